@@ -1,0 +1,223 @@
+/* ka9q_hip.h -- C ABI of libka9q_hip: ka9q-radio's receive DSP hot path on one MI355X (gfx950).
+ *
+ * Part 1 is the drop-in boundary: the same names, argument meaning, struct field order and error
+ * behaviour as the reference's filter.h (filter.h:18-108), so that `radio`, `packet` and `modulate`
+ * link against libka9q_hip.so instead of filter.o.  All arithmetic runs in hand-written HIP kernels;
+ * there is no CPU fallback: every entry point fails (NULL / -1 and a message in ka9q_hip_last_error())
+ * when no gfx950 device is usable.
+ *
+ * Part 2 is the channel-bank extension the reference lacks (its `rotate` argument is "for eventual
+ * use in a demodulator channel bank", filter.c:272): one shared forward FFT per block, C channels,
+ * fused demodulators with device-resident state, many blocks per launch.
+ *
+ * All file:line citations are into the reference tree.
+ */
+#ifndef KA9Q_HIP_H
+#define KA9Q_HIP_H 1
+
+#include <stddef.h>
+#include <stdint.h>
+#include <pthread.h>
+
+#ifdef __cplusplus
+typedef struct kh_cf32 { float re, im; } kh_cf32;   /* layout of C's `complex float` */
+extern "C" {
+#else
+#include <complex.h>
+typedef float _Complex kh_cf32;
+#endif
+
+/* ------------------------------------------------------------------ library */
+/* replaces the global FFTW hooks of main.c:124-127,310 (fftwf_init_threads, ...).  Optional: every
+ * create_* call initialises lazily on device 0.  Returns 0, or -1 if there is no gfx950 device. */
+int ka9q_hip_init(int device);
+const char *ka9q_hip_last_error(void);
+/* replaces fftwf_alloc_complex / fftwf_free for arrays whose ownership passes to a filter
+ * (response of create_filter_output, filter.c:42,183,403; modulate.c:121).  Pinned host memory. */
+void *ka9q_hip_alloc(size_t bytes);
+void ka9q_hip_free(void *p);
+
+/* ------------------------------------------------------------------ Part 1: filter.h */
+enum filtertype { NONE, COMPLEX, CROSS_CONJ, REAL }; /* filter.h:18-23 */
+
+union rc { /* filter.h:26-29 */
+  float *r;
+  kh_cf32 *c;
+};
+
+/* filter.h:55-68.  Field order and types are ABI: callers write input.c[] sample by sample
+ * (radio.c:119,191; packet.c:343), read ilen / impulse_length / fdomain[] (radio.c:124,427-446).
+ * fwd_plan (an fftwf_plan in the reference) holds this library's private handle.
+ * Host arrays are pinned; fdomain[] is coherent when execute_filter_input returns. */
+struct filter_in {
+  enum filtertype in_type;
+  unsigned int ilen;           /* L */
+  unsigned int impulse_length; /* M */
+  kh_cf32 *fdomain;            /* N bins (COMPLEX) or N/2+1 (REAL) */
+  union rc input_buffer;       /* N points */
+  union rc input;              /* input_buffer + M-1, L points */
+  void *fwd_plan;
+  unsigned int blocknum;
+  pthread_mutex_t filter_mutex;
+  pthread_cond_t filter_cond;
+  int fd;
+};
+
+/* filter.h:69-82.  out_type is written by the producer every block (radio.c:126,194); output.c[] is
+ * read (fm.c:56,86) and written (linear.c:91,145) by the demodulators; noise_gain is read by
+ * radio_status.c:173.  rev_plan holds this library's private handle. */
+struct filter_out {
+  struct filter_in *master;
+  enum filtertype out_type;
+  kh_cf32 *response;
+  pthread_mutex_t response_mutex;
+  kh_cf32 *f_fdomain;
+  float noise_gain;
+  union rc output_buffer;      /* N/decimate points */
+  union rc output;             /* output_buffer + N_dec - olen */
+  void *rev_plan;
+  unsigned int decimate;
+  unsigned int olen;
+  unsigned int blocknum;
+};
+
+/* filter.c:57.  NULL on failure (the reference only asserts).  N = L+M-1 must be a power of two
+ * between 64 and 2^22 in this implementation (the reference accepts any FFTW size). */
+struct filter_in *create_filter_input(unsigned int L, unsigned int M, enum filtertype in_type);
+/* filter.c:163.  response may be NULL (set later with set_filter); if not NULL it must come from
+ * ka9q_hip_alloc and becomes filter-owned.  NULL if master is NULL.  N/decimate must be a power of
+ * two between 16 and 8192. */
+struct filter_out *create_filter_output(struct filter_in *master, kh_cf32 *response, unsigned int decimate,
+                                        enum filtertype out_type);
+/* filter.c:212: forward transform of the N-point buffer, blocknum++, wake the outputs, move the
+ * last M-1 samples to the head.  0, or -1 on NULL. */
+int execute_filter_input(struct filter_in *);
+/* filter.c:240: block until a new spectrum exists, select/rotate bins, multiply by the response,
+ * CROSS_CONJ fold, decimating inverse transform.  0, or -1 on NULL. */
+int execute_filter_output(struct filter_out *, int rotate);
+int delete_filter_input(struct filter_in *);   /* filter.c:386; NULL -> 0 */
+int delete_filter_output(struct filter_out *); /* filter.c:396; NULL -> 0 */
+int make_kaiser(float *window, unsigned int M, float beta);           /* filter.c:481 */
+int window_filter(int L, int M, kh_cf32 *response, float beta);       /* filter.c:509 */
+int window_rfilter(int L, int M, kh_cf32 *response, float beta);      /* filter.c:573 */
+int set_filter(struct filter_out *, float low, float high, float kaiser_beta); /* filter.c:660 */
+float noise_gain(struct filter_out const *);                          /* filter.c:631 */
+
+/* The reference's create_filter_input_file (filter.c:96, experimental mmap'd spectrum, no live
+ * caller: main.c:334 is commented out) and notch (filter.c:707-727, no caller) are not provided. */
+
+/* ------------------------------------------------------------------ decimate.h */
+struct hb15_state { /* decimate.h:4-9 */
+  float coeffs[4];
+  float even_samples[4];
+  float odd_samples[4];
+  float old_odd_samples[4];
+};
+/* decimate.h:10-11 with host pointers (staged through the device); in-place (output == input) allowed. */
+void hb15_block(struct hb15_state *state, float *output, float *input, int cnt);
+void hb3_block(float *state, float *output, float *input, int cnt);
+/* The call pattern of hackrf.c:495-509 / airspy.c:508-522 as one launch: `rails` planar float rails
+ * of chunk<<log_decimate samples each (host pointers, rail r at buf + r*rail_stride), decimated in
+ * place by 2^log_decimate; stages j >= stage_threshold use hb3, the rest hb15; hb15[r*log_decimate+j],
+ * hb3[r*log_decimate+j] carry stage j of rail r.  0 or -1. */
+int kh_decimate_rails(struct hb15_state *hb15, float *hb3, int log_decimate, int stage_threshold, float *buf,
+                      size_t rail_stride, int rails, int chunk);
+
+/* ------------------------------------------------------------------ Part 2: channel bank */
+typedef struct kh_bank kh_bank;
+
+enum kh_demod { KH_DEMOD_NONE = 0, KH_DEMOD_FM = 1, KH_DEMOD_LINEAR = 2, KH_DEMOD_AM = 3 };
+/* wire formats of radio.c:80-99,136-178 plus the internal cf32 */
+enum kh_payload { KH_PT_CF32 = 0, KH_PT_IQ12 = 95, KH_PT_IQ16LE = 97, KH_PT_IQ8 = 98, KH_PT_PCM16BE = 10 };
+
+struct kh_bank_config {
+  unsigned int L, M;        /* block and impulse length at the input rate (main.c:326-330) */
+  unsigned int decimate;    /* bank-wide D; N_dec = (L+M-1)/D */
+  unsigned int n_inputs;    /* independent input streams (1 for a wideband bank; P for P pipelines) */
+  unsigned int n_channels;  /* filter_out + demod instances */
+  unsigned int max_blocks;  /* blocks per execute call (T) */
+  int samprate;             /* demod->input.samprate */
+  int payload;              /* enum kh_payload of the raw input ring */
+  int pcm_big_endian;       /* 1: PCM words in network order as audio.c:50,101 sends them */
+  int compute_n0;           /* 1: run compute_n0 (radio.c:422) per input and block */
+  float n0_low, n0_high;    /* demod->filter.low/high (Hz) used by compute_n0 */
+};
+
+struct kh_channel_config {
+  unsigned int input;       /* which input stream */
+  int rotate;               /* execute_filter_output's rotate (filter.c:240) */
+  int out_type;             /* COMPLEX or CROSS_CONJ (demod->filter.isb, radio.c:194) */
+  int demod;                /* enum kh_demod */
+  float low, high;          /* demod->filter.low/high in Hz (set_filter gets low/out_rate, radio.c:408-411) */
+  float kaiser_beta;
+  /* FM (fm.c) */
+  int flat;                 /* opt.flat */
+  float headroom;           /* agc.headroom, amplitude ratio (all demods) */
+  /* linear (linear.c) / AM (am.c) */
+  int pll, square, agc, env;/* opt.* */
+  int channels;             /* output.channels: 1 mono, 2 stereo (linear only) */
+  float hangtime;           /* agc.hangtime, samples */
+  float recovery_rate;      /* agc.recovery_rate, amplitude ratio per sample (am.c: see quirk in DESIGN.md) */
+  float agc_gain;           /* initial agc.gain (main.c:139: +80 dB) */
+  float loop_bw;            /* forced to 5 Hz by linear.c:26 */
+  double shift;             /* post-detection shift in cycles per output sample (radio.c:355-361) */
+};
+
+/* one record per channel per block: the demod->sig / output / agc fields the demod loops write
+ * (fm.c:53-70,116-121,138; linear.c:71-77,98-108,149,156; am.c:90) */
+struct kh_status {
+  float bb_power, snr, foffset, pdeviation, cphase, lock_timer;
+  int pll_lock;
+  float output_level, agc_gain;
+  int squelch_open;
+  float reserved[2];
+};
+/* one record per input per block (radio.c:197-202) */
+struct kh_input_status {
+  float if_power, n0;
+};
+
+kh_bank *kh_bank_create(const struct kh_bank_config *cfg);
+int kh_bank_destroy(kh_bank *);
+int kh_bank_set_channel(kh_bank *, unsigned int ch, const struct kh_channel_config *);
+/* set_second_LO / set_doppler semantics (radio.c:233-240,342-352): f in cycles/sample, rate in
+ * cycles/sample^2, phase kept (osc.c:24-27).  The caller applies radio.c:238's negation. */
+int kh_bank_set_lo(kh_bank *, unsigned int input, double lo2_freq, double doppler_freq, double doppler_rate);
+/* proc_samples' per-packet work (radio.c:132-178) as a bulk upload: append `count` samples of wire
+ * format cfg.payload to input's raw ring (host pointer).  gain_factor = demod->sdr.gain_factor. */
+int kh_bank_write_input(kh_bank *, unsigned int input, const void *payload, size_t count);
+/* lost samples (radio.c:112-131): append `count` zero samples; the NCOs keep stepping */
+int kh_bank_write_zeros(kh_bank *, unsigned int input, size_t count);
+int kh_bank_set_gain(kh_bank *, unsigned int input, float gain_factor);
+/* device address and capacity (in samples) of input's raw ring, for producers that are already on
+ * the GPU.  After filling nblocks*L samples call kh_bank_commit_input. */
+int kh_bank_raw_device_ptr(kh_bank *, unsigned int input, void **dptr, size_t *capacity_samples);
+int kh_bank_commit_input(kh_bank *, unsigned int input, size_t count);
+/* one pass of the hot path over nblocks (<= max_blocks) blocks of every input: convert + mix (a7),
+ * forward FFT (a2), compute_n0 (a8), per channel bin-select x response x IFFT (a4), demod (a9-a12),
+ * scaleclip (a14).  Asynchronous on the bank's stream; kh_bank_sync waits.  0 or -1. */
+int kh_bank_execute(kh_bank *, unsigned int nblocks);
+int kh_bank_sync(kh_bank *);
+/* results of the last execute (host pointers; these calls synchronise) */
+int kh_bank_read_baseband(kh_bank *, unsigned int ch, kh_cf32 *out, size_t nsamples);       /* nblocks*olen */
+int kh_bank_read_pcm(kh_bank *, unsigned int ch, int16_t *out, size_t nwords);               /* nblocks*olen*channels */
+int kh_bank_read_audio(kh_bank *, unsigned int ch, float *out, size_t nwords);               /* float before scaleclip */
+int kh_bank_read_status(kh_bank *, unsigned int ch, struct kh_status *out, size_t nblocks);
+int kh_bank_read_input_status(kh_bank *, unsigned int input, struct kh_input_status *out, size_t nblocks);
+int kh_bank_read_spectrum(kh_bank *, unsigned int input, unsigned int block, kh_cf32 *out);  /* N bins */
+int kh_bank_read_response(kh_bank *, unsigned int ch, kh_cf32 *out, float *noise_gain);      /* N_dec bins */
+/* device-resident views for consumers on the GPU */
+int kh_bank_pcm_device_ptr(kh_bank *, void **dptr, size_t *words_per_channel);
+void *kh_bank_stream(kh_bank *); /* hipStream_t */
+/* per-kernel timing with HIP events on the bank's stream.  Stages: */
+enum kh_stage { KH_STAGE_INGEST = 0, KH_STAGE_FFT1, KH_STAGE_FFT2, KH_STAGE_N0, KH_STAGE_CHAN, KH_STAGE_DEMOD,
+                KH_STAGE_CARRY, KH_STAGE_COUNT };
+int kh_bank_profile(kh_bank *, int enable);
+/* sum of elapsed ms and number of launches per stage since profiling was enabled (synchronises) */
+int kh_bank_stage_times(kh_bank *, float ms[KH_STAGE_COUNT], unsigned int launches[KH_STAGE_COUNT]);
+const char *kh_stage_kernel_name(int stage);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

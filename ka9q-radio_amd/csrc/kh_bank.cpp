@@ -1,0 +1,548 @@
+// kh_bank.cpp -- the channel bank: one shared forward FFT per block, C channels, many blocks per launch.
+//
+// This is the multi-channel receiver the reference only sketches (execute_filter_output's `rotate`,
+// filter.c:270-289, "for eventual use in a demodulator channel bank").  Per execute call, for T blocks:
+//   proc_samples convert + Doppler/LO2 mix + IF power     radio.c:132-204   kh_ingest
+//   execute_filter_input                                  filter.c:212-238  kh_fft_fwd_lds | kh_fft_pass1+2
+//   compute_n0 + smoothing                                radio.c:197-202,422-465   kh_n0_pass<0,1>, kh_n0_final
+//   execute_filter_output per channel                     filter.c:240-384  kh_filter_out
+//   demod_fm / demod_linear / demod_am + scaleclip        fm.c, linear.c, am.c, audio.c:22-28
+// All state (overlap history, NCO phase, demodulator state) stays on the device between calls.
+#include <hip/hip_runtime.h>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+#include "../../include/ka9q_hip.h"
+#include "kh_internal.h"
+
+using namespace kh;
+
+namespace {
+
+struct HostOsc {     // host mirror of struct osc (osc.h:9-17) in phase/frequency form
+  double phase = 0;  // cycles, of the phasor the next step_osc call returns
+  double freq_set = 0, rate = 0; // as given to set_osc
+  double freq_now = 0;           // phase of phasor_step (advances when sweeping)
+  void set(double f, double r) { // osc.c:22-36: phase is kept
+    freq_set = f;
+    rate = r;
+    freq_now = f;
+  }
+  void advance(size_t n) { // n step_osc calls, osc.c:39-50
+    long double const dn = (long double)n;
+    long double ph = (long double)phase + dn * (long double)freq_now + (long double)rate * 0.5L * dn * (dn + 1.0L);
+    ph -= floorl(ph);
+    phase = (double)ph;
+    freq_now += rate * (double)n;
+  }
+};
+
+size_t payload_bytes(int payload, size_t n) {
+  switch (payload) {
+  case KH_PT_IQ16LE:
+  case KH_PT_PCM16BE: return 4 * n;
+  case KH_PT_IQ8: return 2 * n;
+  case KH_PT_IQ12: return 3 * n;
+  default: return 8 * n;
+  }
+}
+
+} // namespace
+
+struct kh_bank {
+  kh_bank_config cfg;
+  int N, ND, olen, T, C, P;
+  hipStream_t stream = nullptr;
+  // device
+  unsigned char *d_raw = nullptr;
+  size_t raw_stride = 0; // bytes per input
+  float2 *d_time[2] = {nullptr, nullptr};
+  size_t time_stride = 0; // samples per input: (M-1) + T*L (+pad)
+  int cur = 0;
+  float2 *d_spec = nullptr, *d_tmp = nullptr;
+  size_t spec_stride = 0; // T*N
+  ChanDesc *d_chans = nullptr;
+  float2 *d_resp = nullptr;
+  DemodDesc *d_ddesc = nullptr;
+  DemodState *d_dstate = nullptr;
+  IngestDesc *d_idesc = nullptr;
+  float2 *d_bb = nullptr;
+  size_t bb_stride = 0; // T*olen
+  float *d_audio = nullptr;
+  int16_t *d_pcm = nullptr;
+  size_t pcm_stride = 0; // 2*T*olen
+  kh_status *d_status = nullptr;
+  kh_input_status *d_istatus = nullptr;
+  float *d_energy = nullptr, *d_n0acc = nullptr, *d_n0state = nullptr, *d_scalar = nullptr;
+  int *d_lists = nullptr; // fm | linear | am, C entries each
+  // host
+  std::vector<ChanDesc> chans;
+  std::vector<DemodDesc> ddesc;
+  std::vector<kh_channel_config> ccfg;
+  std::vector<float> noise_gains;
+  std::vector<HostOsc> lo2, doppler;
+  std::vector<float> gain;
+  std::vector<size_t> fill; // samples present in each input's raw ring
+  std::vector<int> lists;
+  int n_fm = 0, n_lin = 0, n_am = 0;
+  bool chans_dirty = true;
+  unsigned last_blocks = 0;
+  int keep_audio = 1;
+  // profiling
+  bool profiling = false;
+  hipEvent_t ev[KH_STAGE_COUNT + 2] = {};
+  float stage_ms[KH_STAGE_COUNT] = {};
+  unsigned stage_n[KH_STAGE_COUNT] = {};
+};
+
+static bool is_pow2(unsigned v) { return v && !(v & (v - 1)); }
+
+extern "C" {
+
+int kh_bank_destroy(kh_bank *b) {
+  if (!b) return 0;
+  if (b->stream) hipStreamSynchronize(b->stream);
+  void *ptrs[] = {b->d_raw,   b->d_time[0], b->d_time[1], b->d_spec,   b->d_tmp,    b->d_chans,  b->d_resp,
+                  b->d_ddesc, b->d_dstate,  b->d_idesc,   b->d_bb,     b->d_audio,  b->d_pcm,    b->d_status,
+                  b->d_istatus, b->d_energy, b->d_n0acc,  b->d_n0state, b->d_scalar, b->d_lists};
+  for (void *p : ptrs)
+    if (p) hipFree(p);
+  for (auto &e : b->ev)
+    if (e) hipEventDestroy(e);
+  if (b->stream) hipStreamDestroy(b->stream);
+  delete b;
+  return 0;
+}
+
+kh_bank *kh_bank_create(const struct kh_bank_config *cfg) {
+  if (!cfg) return nullptr;
+  if (ensure_init()) return nullptr;
+  unsigned const N = cfg->L + cfg->M - 1;
+  if (cfg->L == 0 || cfg->M == 0 || !is_pow2(N) || N < 256 || N > (1u << 20)) {
+    set_error("kh_bank_create: N = L+M-1 = %u must be a power of two in [256, 2^20]", N);
+    return nullptr;
+  }
+  if (cfg->decimate == 0 || N % cfg->decimate || cfg->L % cfg->decimate) {
+    set_error("kh_bank_create: decimate %u must divide N %u and L %u", cfg->decimate, N, cfg->L);
+    return nullptr;
+  }
+  unsigned const ND = N / cfg->decimate;
+  if (!is_pow2(ND) || ND < 256 || ND > 8192) {
+    set_error("kh_bank_create: N/decimate = %u must be a power of two in [256, 8192]", ND);
+    return nullptr;
+  }
+  if (cfg->n_inputs == 0 || cfg->n_channels == 0 || cfg->max_blocks == 0 || cfg->samprate <= 0) {
+    set_error("kh_bank_create: n_inputs, n_channels, max_blocks and samprate must be positive");
+    return nullptr;
+  }
+  if (N > KH_MAX_SMALL_N && (cfg->L % 2)) {
+    set_error("kh_bank_create: L must be even when N > %d", KH_MAX_SMALL_N);
+    return nullptr;
+  }
+  switch (cfg->payload) {
+  case KH_PT_CF32: case KH_PT_IQ12: case KH_PT_IQ16LE: case KH_PT_IQ8: case KH_PT_PCM16BE: break;
+  default: set_error("kh_bank_create: unknown payload type %d", cfg->payload); return nullptr;
+  }
+  kh_bank *b = new kh_bank();
+  b->cfg = *cfg;
+  b->N = N;
+  b->ND = ND;
+  b->olen = cfg->L / cfg->decimate;
+  b->T = cfg->max_blocks;
+  b->C = cfg->n_channels;
+  b->P = cfg->n_inputs;
+  size_t const T = b->T, C = b->C, P = b->P, L = cfg->L, M = cfg->M;
+  bool ok = KH_HIP(hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking));
+  b->raw_stride = (payload_bytes(cfg->payload, T * L) + 15) & ~(size_t)15;
+  b->time_stride = ((M - 1) + T * L + 1) & ~(size_t)1;
+  b->spec_stride = T * N;
+  b->bb_stride = T * b->olen;
+  b->pcm_stride = 2 * T * b->olen;
+  auto A = [&](auto **p, size_t bytes, bool zero) {
+    if (!ok) return;
+    ok = KH_HIP(hipMalloc((void **)p, bytes ? bytes : 16));
+    if (ok && zero) ok = KH_HIP(hipMemset(*p, 0, bytes ? bytes : 16));
+  };
+  A(&b->d_raw, P * b->raw_stride, true);
+  A(&b->d_time[0], P * b->time_stride * sizeof(float2), true);
+  A(&b->d_time[1], P * b->time_stride * sizeof(float2), true);
+  A(&b->d_spec, P * b->spec_stride * sizeof(float2), false);
+  if (N > KH_MAX_SMALL_N) A(&b->d_tmp, P * b->spec_stride * sizeof(float2), false);
+  A(&b->d_chans, C * sizeof(ChanDesc), true);
+  A(&b->d_resp, C * ND * sizeof(float2), true);
+  A(&b->d_ddesc, C * sizeof(DemodDesc), true);
+  A(&b->d_dstate, C * sizeof(DemodState), true);
+  A(&b->d_idesc, P * sizeof(IngestDesc), true);
+  A(&b->d_bb, C * b->bb_stride * sizeof(float2), true);
+  A(&b->d_audio, C * b->pcm_stride * sizeof(float), true);
+  A(&b->d_pcm, C * b->pcm_stride * sizeof(int16_t), true);
+  A(&b->d_status, C * T * sizeof(kh_status), true);
+  A(&b->d_istatus, P * T * sizeof(kh_input_status), true);
+  A(&b->d_energy, P * T * sizeof(float), true);
+  A(&b->d_n0acc, 3 * P * T * sizeof(float), true);
+  A(&b->d_n0state, P * sizeof(float), false);
+  A(&b->d_scalar, sizeof(float), true);
+  A(&b->d_lists, 3 * C * sizeof(int), true);
+  for (auto &e : b->ev)
+    if (ok) ok = KH_HIP(hipEventCreate(&e));
+  if (ok) { // n0 starts as NaN ("Happens at startup", radio.c:199-202)
+    std::vector<float> nan(P, NAN);
+    ok = KH_HIP(hipMemcpy(b->d_n0state, nan.data(), P * sizeof(float), hipMemcpyHostToDevice));
+  }
+  if (!ok) {
+    kh_bank_destroy(b);
+    return nullptr;
+  }
+  b->chans.assign(C, ChanDesc{0, 0, COMPLEX, 0});
+  b->ddesc.assign(C, DemodDesc{});
+  b->ccfg.assign(C, kh_channel_config{});
+  b->noise_gains.assign(C, NAN);
+  b->lo2.assign(P, HostOsc());
+  b->doppler.assign(P, HostOsc());
+  b->gain.assign(P, 1.0f);
+  b->fill.assign(P, 0);
+  b->lists.assign(3 * C, 0);
+  return b;
+}
+
+int kh_bank_set_channel(kh_bank *b, unsigned int ch, const struct kh_channel_config *c) {
+  if (!b || !c || ch >= (unsigned)b->C) {
+    set_error("kh_bank_set_channel: bad argument");
+    return -1;
+  }
+  if (c->input >= (unsigned)b->P) {
+    set_error("kh_bank_set_channel: input %u out of range", c->input);
+    return -1;
+  }
+  if (c->rotate <= -b->N || c->rotate >= b->N) {
+    set_error("kh_bank_set_channel: |rotate| must be < N");
+    return -1;
+  }
+  if (c->out_type != COMPLEX && c->out_type != CROSS_CONJ) {
+    set_error("kh_bank_set_channel: out_type must be COMPLEX or CROSS_CONJ");
+    return -1;
+  }
+  if (c->demod < KH_DEMOD_NONE || c->demod > KH_DEMOD_AM) {
+    set_error("kh_bank_set_channel: unknown demodulator %d", c->demod);
+    return -1;
+  }
+  float const out_rate = (float)b->cfg.samprate / b->cfg.decimate;
+  // set_filter(out, low/out_rate, high/out_rate, beta): radio.c:408-411, filter.c:660-702
+  float const flow = c->low / out_rate, fhigh = c->high / out_rate;
+  if (std::isnan(flow) || std::isnan(fhigh) || std::isnan(c->kaiser_beta) || fabsf(flow) > 0.5f || fabsf(fhigh) > 0.5f) {
+    set_error("kh_bank_set_channel: filter edges outside +-0.5 of the output rate");
+    return -1;
+  }
+  hipStream_t st = b->stream;
+  float gain = 1.f / (float)b->N;
+  if (c->out_type == CROSS_CONJ) gain *= (float)M_SQRT1_2;
+  float2 *resp = b->d_resp + (size_t)ch * b->ND;
+  int const M_dec = (b->cfg.M - 1) / b->cfg.decimate + 1;
+  if (b->olen + M_dec - 1 != b->ND) {
+    set_error("kh_bank_set_channel: L/D + (M-1)/D != N/D");
+    return -1;
+  }
+  if (launch_brickwall(st, resp, b->ND, flow, fhigh, gain)) return -1;
+  if (launch_window_filter(st, resp, b->olen, M_dec, c->kaiser_beta, 0)) return -1;
+  float const scale = c->out_type == CROSS_CONJ ? 2.f * b->N : (float)b->N;
+  if (launch_noise_gain(st, resp, b->ND, scale, b->d_scalar)) return -1;
+  float ng = NAN;
+  if (!KH_HIP(hipMemcpyAsync(&ng, b->d_scalar, sizeof(float), hipMemcpyDeviceToHost, st))) return -1;
+  if (!KH_HIP(hipStreamSynchronize(st))) return -1;
+  b->noise_gains[ch] = ng;
+  b->ccfg[ch] = *c;
+  b->chans[ch] = ChanDesc{(int)c->input, c->rotate, c->out_type, 0};
+  DemodDesc d{};
+  d.demod = c->demod;
+  d.flat = c->flat;
+  d.headroom = c->headroom;
+  d.dsamprate = out_rate;                                                         // fm.c:27
+  d.fm_gain = (float)((c->headroom * M_1_PI * out_rate) / fabsf(c->low - c->high)); // fm.c:47
+  d.pll = c->pll;
+  d.square = c->square;
+  d.agc = c->agc;
+  d.env = c->env;
+  d.channels = c->channels == 2 ? 2 : 1;
+  d.hangtime = c->hangtime;
+  d.recovery_rate = c->recovery_rate;
+  int const out_samprate_i = (int)out_rate; // demod->output.samprate is an int (radio.h:144)
+  d.out_samprate = (float)out_samprate_i;
+  d.am_hang_samples = c->hangtime * out_samprate_i; // am.c:80
+  {                                                 // init_pll(&pll, loop_bw, 1/sqrt2, 0, samprate), osc.c:64-85
+    float const samptime = (float)(1. / (float)out_samprate_i);
+    float nf = c->loop_bw;
+    nf *= samptime;
+    float const vcogain = (float)(2 * M_PI);
+    float const natfreq = (float)(nf * 2 * M_PI);
+    float const tau1 = vcogain * 1.f / (natfreq * natfreq);
+    float const tau2 = (float)(2 * (float)M_SQRT1_2 / natfreq);
+    d.pll_prop_gain = tau2 / tau1;
+    d.pll_integrator_gain = 1 / tau1;
+  }
+  d.lock_limit = (int)(1.f * out_samprate_i); // linear.c:34-36
+  d.shift_freq = c->shift;
+  b->ddesc[ch] = d;
+  // fresh demodulator state, as at thread start (fm.c:26-33, linear.c:29-44, am.c:26-35)
+  DemodState s{};
+  s.vco_re = 1.0; // linear.c:40 leaves struct pll uninitialised; set_osc's is_phasor_init makes it 1 (osc.c:24-27)
+  s.shift_re = 1.0;
+  s.agc_gain = c->agc_gain;
+  s.snr = 0.f; // linear.c:44
+  {            // am.c:21,31: dB2voltage(recovery_rate * samptime)
+    float const samptime = b->cfg.decimate / (float)b->cfg.samprate;
+    s.am_recovery_per_sample = powf(10.f, (c->recovery_rate * samptime) / 20.f);
+  }
+  if (!KH_HIP(hipMemcpyAsync(b->d_dstate + ch, &s, sizeof(s), hipMemcpyHostToDevice, st))) return -1;
+  if (!KH_HIP(hipStreamSynchronize(st))) return -1;
+  b->chans_dirty = true;
+  return 0;
+}
+
+int kh_bank_set_lo(kh_bank *b, unsigned int input, double lo2_freq, double doppler_freq, double doppler_rate) {
+  if (!b || input >= (unsigned)b->P) return -1;
+  b->lo2[input].set(lo2_freq, 0.0);                    // set_second_LO, radio.c:350
+  b->doppler[input].set(doppler_freq, doppler_rate);   // set_doppler, radio.c:238
+  return 0;
+}
+int kh_bank_set_gain(kh_bank *b, unsigned int input, float gain_factor) {
+  if (!b || input >= (unsigned)b->P) return -1;
+  b->gain[input] = gain_factor;
+  return 0;
+}
+
+int kh_bank_write_input(kh_bank *b, unsigned int input, const void *payload, size_t count) {
+  if (!b || input >= (unsigned)b->P || (!payload && count)) return -1;
+  size_t const cap = (size_t)b->T * b->cfg.L;
+  if (b->fill[input] + count > cap) {
+    set_error("kh_bank_write_input: ring overflow (%zu + %zu > %zu samples)", b->fill[input], count, cap);
+    return -1;
+  }
+  unsigned char *dst = b->d_raw + input * b->raw_stride + payload_bytes(b->cfg.payload, b->fill[input]);
+  if (!KH_HIP(hipMemcpyAsync(dst, payload, payload_bytes(b->cfg.payload, count), hipMemcpyHostToDevice, b->stream)))
+    return -1;
+  if (!KH_HIP(hipStreamSynchronize(b->stream))) return -1; // the caller may reuse its buffer
+  b->fill[input] += count;
+  return 0;
+}
+int kh_bank_write_zeros(kh_bank *b, unsigned int input, size_t count) {
+  if (!b || input >= (unsigned)b->P) return -1;
+  size_t const cap = (size_t)b->T * b->cfg.L;
+  if (b->fill[input] + count > cap) {
+    set_error("kh_bank_write_zeros: ring overflow");
+    return -1;
+  }
+  unsigned char *dst = b->d_raw + input * b->raw_stride + payload_bytes(b->cfg.payload, b->fill[input]);
+  if (!KH_HIP(hipMemsetAsync(dst, 0, payload_bytes(b->cfg.payload, count), b->stream))) return -1;
+  b->fill[input] += count;
+  return 0;
+}
+int kh_bank_raw_device_ptr(kh_bank *b, unsigned int input, void **dptr, size_t *capacity_samples) {
+  if (!b || input >= (unsigned)b->P || !dptr) return -1;
+  *dptr = b->d_raw + input * b->raw_stride;
+  if (capacity_samples) *capacity_samples = (size_t)b->T * b->cfg.L;
+  return 0;
+}
+int kh_bank_commit_input(kh_bank *b, unsigned int input, size_t count) {
+  if (!b || input >= (unsigned)b->P) return -1;
+  if (count > (size_t)b->T * b->cfg.L) return -1;
+  b->fill[input] = count;
+  return 0;
+}
+
+static int upload_channels(kh_bank *b) {
+  b->n_fm = b->n_lin = b->n_am = 0;
+  int const C = b->C;
+  for (int ch = 0; ch < C; ch++) {
+    switch (b->ddesc[ch].demod) {
+    case KH_DEMOD_FM: b->lists[b->n_fm++] = ch; break;
+    case KH_DEMOD_LINEAR: b->lists[C + b->n_lin++] = ch; break;
+    case KH_DEMOD_AM: b->lists[2 * C + b->n_am++] = ch; break;
+    default: break;
+    }
+  }
+  hipStream_t st = b->stream;
+  bool ok = KH_HIP(hipMemcpyAsync(b->d_chans, b->chans.data(), C * sizeof(ChanDesc), hipMemcpyHostToDevice, st));
+  ok = ok && KH_HIP(hipMemcpyAsync(b->d_ddesc, b->ddesc.data(), C * sizeof(DemodDesc), hipMemcpyHostToDevice, st));
+  ok = ok && KH_HIP(hipMemcpyAsync(b->d_lists, b->lists.data(), 3 * C * sizeof(int), hipMemcpyHostToDevice, st));
+  ok = ok && KH_HIP(hipStreamSynchronize(st));
+  if (ok) b->chans_dirty = false;
+  return ok ? 0 : -1;
+}
+
+int kh_bank_execute(kh_bank *b, unsigned int nblocks) {
+  if (!b) return -1;
+  if (nblocks == 0 || nblocks > (unsigned)b->T) {
+    set_error("kh_bank_execute: nblocks %u outside [1, %d]", nblocks, b->T);
+    return -1;
+  }
+  if (ensure_init()) return -1;
+  int const L = b->cfg.L, M = b->cfg.M, N = b->N, P = b->P, C = b->C;
+  size_t const need = (size_t)nblocks * L;
+  for (int i = 0; i < P; i++)
+    if (b->fill[i] < need) {
+      set_error("kh_bank_execute: input %d holds %zu samples, %zu needed", i, b->fill[i], need);
+      return -1;
+    }
+  if (b->chans_dirty && upload_channels(b)) return -1;
+  hipStream_t st = b->stream;
+  // oscillator snapshot for this launch
+  std::vector<IngestDesc> id(P);
+  for (int i = 0; i < P; i++) {
+    HostOsc &lo = b->lo2[i], &dp = b->doppler[i];
+    id[i].gain_factor = b->gain[i];
+    id[i].lo2 = NcoArgs{lo.phase, lo.freq_now, lo.rate, !(lo.freq_now == 0 && lo.rate == 0 && lo.phase == 0), 0};
+    id[i].doppler = NcoArgs{dp.phase, dp.freq_now, dp.rate, dp.freq_set != 0, 0}; // radio.c:180
+    lo.advance(need);
+    if (dp.freq_set != 0) dp.advance(need);
+  }
+  if (!KH_HIP(hipMemcpyAsync(b->d_idesc, id.data(), P * sizeof(IngestDesc), hipMemcpyHostToDevice, st))) return -1;
+  if (!KH_HIP(hipStreamSynchronize(st))) return -1; // id goes out of scope
+
+  bool const prof = b->profiling;
+  int e = 0;
+  auto mark = [&]() {
+    if (prof) hipEventRecord(b->ev[e], st);
+    e++;
+  };
+  float2 *time = b->d_time[b->cur];
+  mark(); // 0
+  if (launch_ingest(st, b->d_raw, b->raw_stride, b->cfg.payload, time + (M - 1), b->time_stride, b->d_idesc, b->d_energy,
+                    L, nblocks, P))
+    return -1;
+  mark(); // 1
+  // launch_forward_fft records the mid event (ev[2]) between the two passes itself
+  if (launch_forward_fft(st, time, b->time_stride, 0, b->d_spec, b->d_tmp, b->spec_stride, N, L, nblocks, P,
+                         prof ? b->ev[2] : nullptr))
+    return -1;
+  e = 3;
+  mark(); // 3
+  if (launch_n0(st, b->cfg.compute_n0 ? b->d_spec : nullptr, b->spec_stride, N, b->cfg.samprate, b->cfg.n0_low,
+                b->cfg.n0_high, b->d_energy, L, b->d_n0state, b->d_n0acc, b->d_istatus, nblocks, P))
+    return -1;
+  mark(); // 4
+  if (launch_filter_output(st, b->d_spec, b->spec_stride, N, 0, b->d_chans, b->d_resp, b->ND, b->olen, b->d_bb,
+                           b->bb_stride, nblocks, C))
+    return -1;
+  mark(); // 5
+  if (launch_demod(st, b->d_bb, b->bb_stride, b->olen, nblocks, C, b->d_ddesc, b->d_dstate,
+                   b->keep_audio ? b->d_audio : nullptr, b->d_pcm, b->pcm_stride, b->cfg.pcm_big_endian, b->d_status,
+                   b->T, b->d_lists, b->n_fm, b->d_lists + C, b->n_lin, b->d_lists + 2 * C, b->n_am))
+    return -1;
+  mark(); // 6
+  // overlap-save history for the next call (filter.c:230), into the other buffer
+  if (launch_carry(st, time + need, b->d_time[b->cur ^ 1], b->time_stride * sizeof(float2), (size_t)(M - 1) * sizeof(float2),
+                   P))
+    return -1;
+  mark(); // 7
+  b->cur ^= 1;
+  // consume the raw ring
+  for (int i = 0; i < P; i++) {
+    size_t const rest = b->fill[i] - need;
+    if (rest) {
+      unsigned char *base = b->d_raw + i * b->raw_stride;
+      // rest < need is not guaranteed: stage through the (now idle) tmp-free path with an ordered device copy
+      if (rest <= need) {
+        if (!KH_HIP(hipMemcpyAsync(base, base + payload_bytes(b->cfg.payload, need), payload_bytes(b->cfg.payload, rest),
+                                   hipMemcpyDeviceToDevice, st)))
+          return -1;
+      } else {
+        set_error("kh_bank_execute: more than one launch of samples queued; consume them first");
+        return -1;
+      }
+    }
+    b->fill[i] = rest;
+  }
+  b->last_blocks = nblocks;
+  if (prof) {
+    if (!KH_HIP(hipStreamSynchronize(st))) return -1;
+    for (int s = 0; s < KH_STAGE_COUNT; s++) {
+      float ms = 0.f;
+      if (hipEventElapsedTime(&ms, b->ev[s], b->ev[s + 1]) == hipSuccess) {
+        b->stage_ms[s] += ms;
+        b->stage_n[s]++;
+      }
+    }
+  }
+  return 0;
+}
+
+int kh_bank_sync(kh_bank *b) {
+  if (!b) return -1;
+  return KH_HIP(hipStreamSynchronize(b->stream)) ? 0 : -1;
+}
+
+static int read_back(kh_bank *b, void *dst, const void *src, size_t bytes) {
+  if (!KH_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, b->stream))) return -1;
+  return KH_HIP(hipStreamSynchronize(b->stream)) ? 0 : -1;
+}
+int kh_bank_read_baseband(kh_bank *b, unsigned int ch, kh_cf32 *out, size_t nsamples) {
+  if (!b || ch >= (unsigned)b->C || !out || nsamples > b->bb_stride) return -1;
+  return read_back(b, out, b->d_bb + ch * b->bb_stride, nsamples * sizeof(float2));
+}
+int kh_bank_read_pcm(kh_bank *b, unsigned int ch, int16_t *out, size_t nwords) {
+  if (!b || ch >= (unsigned)b->C || !out || nwords > b->pcm_stride) return -1;
+  return read_back(b, out, b->d_pcm + ch * b->pcm_stride, nwords * sizeof(int16_t));
+}
+int kh_bank_read_audio(kh_bank *b, unsigned int ch, float *out, size_t nwords) {
+  if (!b || ch >= (unsigned)b->C || !out || nwords > b->pcm_stride) return -1;
+  return read_back(b, out, b->d_audio + ch * b->pcm_stride, nwords * sizeof(float));
+}
+int kh_bank_read_status(kh_bank *b, unsigned int ch, struct kh_status *out, size_t nblocks) {
+  if (!b || ch >= (unsigned)b->C || !out || nblocks > (size_t)b->T) return -1;
+  return read_back(b, out, b->d_status + (size_t)ch * b->T, nblocks * sizeof(kh_status));
+}
+int kh_bank_read_input_status(kh_bank *b, unsigned int input, struct kh_input_status *out, size_t nblocks) {
+  if (!b || input >= (unsigned)b->P || !out || nblocks > b->last_blocks) return -1;
+  // records of one launch are packed [input][last_blocks]
+  return read_back(b, out, b->d_istatus + (size_t)input * b->last_blocks, nblocks * sizeof(kh_input_status));
+}
+int kh_bank_read_spectrum(kh_bank *b, unsigned int input, unsigned int block, kh_cf32 *out) {
+  if (!b || input >= (unsigned)b->P || block >= (unsigned)b->T || !out) return -1;
+  return read_back(b, out, b->d_spec + input * b->spec_stride + (size_t)block * b->N, b->N * sizeof(float2));
+}
+int kh_bank_read_response(kh_bank *b, unsigned int ch, kh_cf32 *out, float *noise_gain_out) {
+  if (!b || ch >= (unsigned)b->C) return -1;
+  if (noise_gain_out) *noise_gain_out = b->noise_gains[ch];
+  if (!out) return 0;
+  return read_back(b, out, b->d_resp + (size_t)ch * b->ND, b->ND * sizeof(float2));
+}
+int kh_bank_pcm_device_ptr(kh_bank *b, void **dptr, size_t *words_per_channel) {
+  if (!b || !dptr) return -1;
+  *dptr = b->d_pcm;
+  if (words_per_channel) *words_per_channel = b->pcm_stride;
+  return 0;
+}
+void *kh_bank_stream(kh_bank *b) { return b ? (void *)b->stream : nullptr; }
+
+int kh_bank_profile(kh_bank *b, int enable) {
+  if (!b) return -1;
+  b->profiling = enable != 0;
+  memset(b->stage_ms, 0, sizeof(b->stage_ms));
+  memset(b->stage_n, 0, sizeof(b->stage_n));
+  return 0;
+}
+int kh_bank_stage_times(kh_bank *b, float ms[KH_STAGE_COUNT], unsigned int launches[KH_STAGE_COUNT]) {
+  if (!b) return -1;
+  for (int s = 0; s < KH_STAGE_COUNT; s++) {
+    if (ms) ms[s] = b->stage_ms[s];
+    if (launches) launches[s] = b->stage_n[s];
+  }
+  return 0;
+}
+const char *kh_stage_kernel_name(int stage) {
+  switch (stage) {
+  case KH_STAGE_INGEST: return "kh_ingest";
+  case KH_STAGE_FFT1: return "kh_fft_pass1|kh_fft_fwd_lds";
+  case KH_STAGE_FFT2: return "kh_fft_pass2";
+  case KH_STAGE_N0: return "kh_n0_pass+kh_n0_final";
+  case KH_STAGE_CHAN: return "kh_filter_out";
+  case KH_STAGE_DEMOD: return "kh_demod_fm|kh_demod_linear|kh_demod_am";
+  case KH_STAGE_CARRY: return "kh_carry";
+  }
+  return "";
+}
+
+} // extern "C"

@@ -1,0 +1,491 @@
+// kh_fft_kernels.hip -- forward overlap-save transform, per-channel filter output, response design.
+//
+// Reference behaviour restated here (citations into the reference tree):
+//   execute_filter_input   filter.c:212-238   forward DFT of N = L+M-1 points per block
+//   execute_filter_output  filter.c:240-384   bin select/rotate x response, CROSS_CONJ, backward DFT of N/D points
+//   set_filter/window_filter/window_rfilter/make_kaiser/i0/noise_gain  filter.c:410-702
+//
+// Roofline: everything here streams; HBM bound.  No MFMA: nothing is a dense contraction.
+#include "kh_internal.h"
+#include "kh_fft.cuh"
+
+namespace kh {
+
+enum { FT_NONE = 0, FT_COMPLEX = 1, FT_CROSS_CONJ = 2, FT_REAL = 3 }; // filter.h:18-23
+
+// ================================================================ forward FFT, N <= 8192: one workgroup per block
+// algorithmic bytes per launch: nblocks*ninputs*(8N read + 8N write)
+template <int R, int NT>
+__global__ __launch_bounds__(NT) void kh_fft_fwd_lds(const void *__restrict__ time, size_t in_stride, int real_input,
+                                                     float2 *__restrict__ spec, size_t spec_in_stride, int L,
+                                                     const float2 *__restrict__ tw) {
+  __shared__ __attribute__((aligned(16))) float2 buf[R];
+  int const tid = threadIdx.x;
+  int const b = blockIdx.x, i = blockIdx.y;
+  if (real_input) {
+    const float2 *src = reinterpret_cast<const float2 *>(static_cast<const float *>(time) + i * in_stride + (size_t)b * L);
+    for (int k = tid; k < R / 2; k += NT) { // two reals per lane
+      float2 v = src[k];
+      buf[2 * k] = make_float2(v.x, 0.f);
+      buf[2 * k + 1] = make_float2(v.y, 0.f);
+    }
+  } else {
+    const float4 *src = reinterpret_cast<const float4 *>(static_cast<const float2 *>(time) + i * in_stride + (size_t)b * L);
+    for (int k = tid; k < R / 2; k += NT) reinterpret_cast<float4 *>(buf)[k] = src[k];
+  }
+  __syncthreads();
+  lds_fft<R, 1, NT, 1, 1, false, -1>(buf, tw, tid);
+  float4 *dst = reinterpret_cast<float4 *>(spec + i * spec_in_stride + (size_t)b * R);
+  for (int k = tid; k < R / 2; k += NT) dst[k] = reinterpret_cast<float4 *>(buf)[k];
+}
+
+// ================================================================ forward FFT, N = N1*N2 > 8192: four-step, two launches
+// X[k1 + N1*k2] = sum_{n2} W_N^{n2 k1} [ sum_{n1} x[n1*N2 + n2] W_N1^{n1 k1} ] W_N2^{n2 k2}
+// pass 1: 16 adjacent columns n2 per workgroup (128-byte row segments), N1-point transforms down the columns,
+//         four-step twiddle, result A[k1][n2] written in the input's own layout.
+// pass 2: 16 adjacent rows k1 per workgroup, N2-point transforms along the rows, transposed store.
+// algorithmic bytes per launch, each pass: nblocks*ninputs*(8N read + 8N write)
+constexpr int TILE_W = 16;
+
+template <int R, int NT>
+__global__ __launch_bounds__(NT) void kh_fft_pass1(const float2 *__restrict__ time, size_t in_stride,
+                                                   float2 *__restrict__ tmp, size_t spec_in_stride, int N2, int L,
+                                                   const float2 *__restrict__ tw, BigTwiddle bt) {
+  constexpr int W = TILE_W;
+  __shared__ __attribute__((aligned(16))) float2 buf[R * W];
+  int const tid = threadIdx.x;
+  int const tile = blockIdx.x, b = blockIdx.y, i = blockIdx.z;
+  int const cp = tid & 7;   // column pair inside the tile
+  int const r0 = tid >> 3;
+  const float2 *src = time + i * in_stride + (size_t)b * L + tile * W + 2 * cp;
+#pragma unroll 4
+  for (int r = r0; r < R; r += NT / 8)
+    *reinterpret_cast<float4 *>(buf + r * W + 2 * cp) = *reinterpret_cast<const float4 *>(src + (size_t)r * N2);
+  __syncthreads();
+  lds_fft<R, W, NT, W, 1, true, -1>(buf, tw, tid);
+  size_t const N = (size_t)R * N2;
+  float2 *dst = tmp + i * spec_in_stride + (size_t)b * N + tile * W + 2 * cp;
+  int const n2 = tile * W + 2 * cp;
+#pragma unroll 4
+  for (int k1 = r0; k1 < R; k1 += NT / 8) {
+    float4 v = *reinterpret_cast<float4 *>(buf + k1 * W + 2 * cp);
+    unsigned const i0 = (unsigned)n2 * (unsigned)k1; // < N
+    unsigned const i1 = i0 + (unsigned)k1;
+    float2 const w0 = cmul(bt.coarse[i0 >> 10], bt.fine[i0 & 1023]);
+    float2 const w1 = cmul(bt.coarse[i1 >> 10], bt.fine[i1 & 1023]);
+    float2 const a = cmul(make_float2(v.x, v.y), w0);
+    float2 const c = cmul(make_float2(v.z, v.w), w1);
+    *reinterpret_cast<float4 *>(dst + (size_t)k1 * N2) = make_float4(a.x, a.y, c.x, c.y);
+  }
+}
+
+template <int R, int NT>
+__global__ __launch_bounds__(NT) void kh_fft_pass2(const float2 *__restrict__ tmp, float2 *__restrict__ spec,
+                                                   size_t spec_in_stride, int N1, const float2 *__restrict__ tw) {
+  constexpr int W = TILE_W;
+  constexpr int SC = R + 2; // row pitch: even (16-byte rows) and bank-skewed for the transposed read
+  __shared__ __attribute__((aligned(16))) float2 buf[W * SC];
+  int const tid = threadIdx.x;
+  int const tile = blockIdx.x, b = blockIdx.y, i = blockIdx.z;
+  size_t const N = (size_t)R * N1;
+  const float2 *src = tmp + i * spec_in_stride + (size_t)b * N + (size_t)tile * W * R;
+#pragma unroll 4
+  for (int idx = tid; idx < W * R / 2; idx += NT) {
+    int const c = idx / (R / 2), j = idx % (R / 2);
+    *reinterpret_cast<float4 *>(buf + c * SC + 2 * j) = reinterpret_cast<const float4 *>(src + (size_t)c * R)[j];
+  }
+  __syncthreads();
+  lds_fft<R, W, NT, 1, SC, false, -1>(buf, tw, tid);
+  int const cp = tid & 7;
+  float2 *dst = spec + i * spec_in_stride + (size_t)b * N + tile * W + 2 * cp;
+#pragma unroll 4
+  for (int k2 = tid >> 3; k2 < R; k2 += NT / 8) {
+    float2 const a = buf[(2 * cp) * SC + k2];
+    float2 const c = buf[(2 * cp + 1) * SC + k2];
+    *reinterpret_cast<float4 *>(dst + (size_t)k2 * N1) = make_float4(a.x, a.y, c.x, c.y);
+  }
+}
+
+template <int R>
+static int launch_small(hipStream_t st, const void *time, size_t in_stride, int real_input, float2 *spec,
+                        size_t spec_in_stride, int L, int nblocks, int ninputs) {
+  constexpr int NT = (R / 4 < 256) ? R / 4 : 256;
+  const float2 *tw = twiddle_table(R);
+  if (!tw) return -1;
+  hipLaunchKernelGGL((kh_fft_fwd_lds<R, NT>), dim3(nblocks, ninputs), dim3(NT), 0, st, time, in_stride, real_input, spec,
+                     spec_in_stride, L, tw);
+  return KH_HIP(hipGetLastError()) ? 0 : -1;
+}
+
+template <int R>
+static int launch_p1(hipStream_t st, const float2 *time, size_t in_stride, float2 *tmp, size_t spec_in_stride, int N2,
+                     int L, int nblocks, int ninputs) {
+  constexpr int NT = R / 2;
+  const float2 *tw = twiddle_table(R);
+  BigTwiddle bt = big_twiddle(R * N2);
+  if (!tw || !bt.fine) return -1;
+  hipLaunchKernelGGL((kh_fft_pass1<R, NT>), dim3(N2 / TILE_W, nblocks, ninputs), dim3(NT), 0, st, time, in_stride, tmp,
+                     spec_in_stride, N2, L, tw, bt);
+  return KH_HIP(hipGetLastError()) ? 0 : -1;
+}
+template <int R>
+static int launch_p2(hipStream_t st, const float2 *tmp, float2 *spec, size_t spec_in_stride, int N1, int nblocks,
+                     int ninputs) {
+  constexpr int NT = R / 2;
+  const float2 *tw = twiddle_table(R);
+  if (!tw) return -1;
+  hipLaunchKernelGGL((kh_fft_pass2<R, NT>), dim3(N1 / TILE_W, nblocks, ninputs), dim3(NT), 0, st, tmp, spec,
+                     spec_in_stride, N1, tw);
+  return KH_HIP(hipGetLastError()) ? 0 : -1;
+}
+
+static int ilog2(unsigned v) {
+  int e = 0;
+  while ((1u << e) < v) e++;
+  return e;
+}
+
+int launch_forward_fft(hipStream_t st, const void *time, size_t in_stride, int real_input, float2 *spec, float2 *tmp,
+                       size_t spec_in_stride, int N, int L, int nblocks, int ninputs, hipEvent_t mid_event) {
+  if (N < 256 || (N & (N - 1)) || N > (1 << 20)) {
+    set_error("forward FFT size %d unsupported (power of two in [256, 2^20] required)", N);
+    return -1;
+  }
+  if (nblocks <= 0 || ninputs <= 0) return 0;
+  if (N <= KH_MAX_SMALL_N) {
+    int rc = -1;
+    switch (N) {
+    case 256: rc = launch_small<256>(st, time, in_stride, real_input, spec, spec_in_stride, L, nblocks, ninputs); break;
+    case 512: rc = launch_small<512>(st, time, in_stride, real_input, spec, spec_in_stride, L, nblocks, ninputs); break;
+    case 1024: rc = launch_small<1024>(st, time, in_stride, real_input, spec, spec_in_stride, L, nblocks, ninputs); break;
+    case 2048: rc = launch_small<2048>(st, time, in_stride, real_input, spec, spec_in_stride, L, nblocks, ninputs); break;
+    case 4096: rc = launch_small<4096>(st, time, in_stride, real_input, spec, spec_in_stride, L, nblocks, ninputs); break;
+    case 8192: rc = launch_small<8192>(st, time, in_stride, real_input, spec, spec_in_stride, L, nblocks, ninputs); break;
+    }
+    if (mid_event) hipEventRecord(mid_event, st);
+    return rc;
+  }
+  if (real_input) {
+    set_error("REAL input is limited to N <= %d", KH_MAX_SMALL_N);
+    return -1;
+  }
+  if (L % 2) {
+    set_error("L must be even for N > %d", KH_MAX_SMALL_N);
+    return -1;
+  }
+  int const e = ilog2((unsigned)N);
+  int const N1 = 1 << ((e + 1) / 2), N2 = 1 << (e / 2);
+  const float2 *t = static_cast<const float2 *>(time);
+  int rc = -1;
+  switch (N1) {
+  case 128: rc = launch_p1<128>(st, t, in_stride, tmp, spec_in_stride, N2, L, nblocks, ninputs); break;
+  case 256: rc = launch_p1<256>(st, t, in_stride, tmp, spec_in_stride, N2, L, nblocks, ninputs); break;
+  case 512: rc = launch_p1<512>(st, t, in_stride, tmp, spec_in_stride, N2, L, nblocks, ninputs); break;
+  case 1024: rc = launch_p1<1024>(st, t, in_stride, tmp, spec_in_stride, N2, L, nblocks, ninputs); break;
+  }
+  if (rc) return rc;
+  if (mid_event) hipEventRecord(mid_event, st);
+  switch (N2) {
+  case 128: rc = launch_p2<128>(st, tmp, spec, spec_in_stride, N1, nblocks, ninputs); break;
+  case 256: rc = launch_p2<256>(st, tmp, spec, spec_in_stride, N1, nblocks, ninputs); break;
+  case 512: rc = launch_p2<512>(st, tmp, spec, spec_in_stride, N1, nblocks, ninputs); break;
+  case 1024: rc = launch_p2<1024>(st, tmp, spec, spec_in_stride, N1, nblocks, ninputs); break;
+  default: rc = -1;
+  }
+  return rc;
+}
+
+// ================================================================ filter output: one workgroup per (channel, block)
+// algorithmic bytes per workgroup: 8*ND spectrum bins + 8*ND response + 8*olen (4*olen REAL) output
+template <int ND, int NT>
+__global__ __launch_bounds__(NT) void kh_filter_out(const float2 *__restrict__ spec, size_t spec_in_stride, int N,
+                                                    int in_real, const ChanDesc *__restrict__ chans,
+                                                    const float2 *__restrict__ response, int olen, void *out,
+                                                    size_t out_stride, const float2 *__restrict__ tw) {
+  __shared__ __attribute__((aligned(16))) float2 f[ND];
+  int const tid = threadIdx.x;
+  int const ch = blockIdx.x, b = blockIdx.y;
+  ChanDesc const cd = chans[ch];
+  const float2 *fd = spec + (size_t)cd.input * spec_in_stride + (size_t)b * N;
+  const float2 *resp = response + (size_t)ch * ND;
+  bool const out_real = cd.out_type == FT_REAL;
+  int const rotate = cd.rotate;
+
+  if (!in_real && !out_real) { // complex -> complex, filter.c:274-289
+    int m0 = N - ND / 2 + 1 + rotate;
+    if (m0 >= N) m0 -= N;
+    if (m0 < 0) m0 += N;
+    for (int i = tid; i < ND; i += NT) {
+      int p = ND / 2 + 1 + i;
+      if (p >= ND) p -= ND;
+      int m = m0 + i;
+      if (m >= N) m -= N;
+      f[p] = cmul(resp[p], fd[m]);
+    }
+  } else {
+    int m0 = rotate;
+    if (m0 < 0) m0 += N;
+    if (in_real && out_real) { // real -> real, filter.c:290-299 (bins above ND/2 are rebuilt below)
+      for (int p = tid; p <= ND / 2; p += NT) {
+        int m = m0 + p;
+        if (m >= N) m -= N;
+        f[p] = cmul(resp[p], fd[m]);
+      }
+    } else if (!in_real && out_real) { // complex -> real, filter.c:300-317
+      for (int p = tid; p <= ND / 2; p += NT) {
+        int m = m0 + p;
+        if (m >= N) m -= N;
+        float2 v = cmul(resp[p], fd[m]);
+        if (p > 0 && p < ND / 2) v = cadd(v, cconj(cmul(resp[ND - p], fd[m])));
+        f[p] = v;
+      }
+    } else { // real -> complex, filter.c:318-335
+      for (int p = tid; p <= ND / 2; p += NT) {
+        int m = m0 + p;
+        if (m >= N) m -= N;
+        float2 const x = fd[m];
+        f[p] = cmul(resp[p], x);
+        if (p > 0 && p < ND / 2) f[ND - p] = cmul(resp[ND - p], cconj(x));
+      }
+    }
+  }
+  __syncthreads();
+  if (cd.out_type == FT_CROSS_CONJ) { // filter.c:371-381
+    for (int p = 1 + tid; p < ND / 2; p += NT) {
+      int const dn = ND - p;
+      float2 const pos = f[p], neg = f[dn];
+      f[p] = cadd(pos, cconj(neg));
+      f[dn] = csub(neg, cconj(pos));
+    }
+    __syncthreads();
+  }
+  if (out_real) { // c2r (filter.c:207,382): Hermitian extension, imaginary parts of DC and Nyquist ignored
+    for (int p = tid; p <= ND / 2; p += NT) {
+      float2 v = f[p];
+      if (p == 0 || p == ND / 2)
+        f[p] = make_float2(v.x, 0.f);
+      else
+        f[ND - p] = cconj(v);
+    }
+    __syncthreads();
+  }
+  lds_fft<ND, 1, NT, 1, 1, false, +1>(f, tw, tid);
+  // the valid part of the circular convolution is the last olen points (filter.c:197,206)
+  if (out_real) {
+    float *o = static_cast<float *>(out) + (size_t)ch * out_stride + (size_t)b * olen;
+    for (int n = tid; n < olen; n += NT) o[n] = f[ND - olen + n].x;
+  } else {
+    float2 *o = static_cast<float2 *>(out) + (size_t)ch * out_stride + (size_t)b * olen;
+    for (int n = tid; n < olen; n += NT) o[n] = f[ND - olen + n];
+  }
+}
+
+template <int ND>
+static int launch_fo(hipStream_t st, const float2 *spec, size_t spec_in_stride, int N, int in_real, const ChanDesc *chans,
+                     const float2 *response, int olen, void *out, size_t out_stride, int nblocks, int nchan) {
+  constexpr int NT = (ND / 4 < 256) ? ND / 4 : 256;
+  const float2 *tw = twiddle_table(ND);
+  if (!tw) return -1;
+  hipLaunchKernelGGL((kh_filter_out<ND, NT>), dim3(nchan, nblocks), dim3(NT), 0, st, spec, spec_in_stride, N, in_real,
+                     chans, response, olen, out, out_stride, tw);
+  return KH_HIP(hipGetLastError()) ? 0 : -1;
+}
+
+int launch_filter_output(hipStream_t st, const float2 *spec, size_t spec_in_stride, int N, int in_real,
+                         const ChanDesc *chans, const float2 *response, int ND, int olen, void *out, size_t out_stride,
+                         int nblocks, int nchan) {
+  if (nblocks <= 0 || nchan <= 0) return 0;
+  if (olen > ND || ND > N) {
+    set_error("filter output: olen %d > N_dec %d or N_dec > N %d", olen, ND, N);
+    return -1;
+  }
+#define FO(n) \
+  case n: return launch_fo<n>(st, spec, spec_in_stride, N, in_real, chans, response, olen, out, out_stride, nblocks, nchan)
+  switch (ND) {
+    FO(256);
+    FO(512);
+    FO(1024);
+    FO(2048);
+    FO(4096);
+    FO(8192);
+  }
+#undef FO
+  set_error("decimated FFT size %d unsupported (power of two in [256, 8192] required)", ND);
+  return -1;
+}
+
+// ================================================================ response design (control path, but on the device)
+__device__ float dev_i0f(float z) { // filter.c:410-421
+  float const t = (z * z) / 4;
+  float sum = 1 + t;
+  float term = t;
+  for (int k = 2; k < 40; k++) {
+    term *= t / (k * k);
+    sum += term;
+    if ((double)term < 1e-12 * (double)sum) break;
+  }
+  return sum;
+}
+// one element of make_kaiser, filter.c:481-501
+__device__ float dev_kaiser(int n, int M, float numc, float inv_denom, float pc) {
+  if ((M & 1) && n == (M - 1) / 2) return 1.f;
+  int const nn = n < M / 2 ? n : M - 1 - n;
+  float const p = pc * nn - 1;
+  return dev_i0f(numc * sqrtf(1 - p * p)) * inv_denom;
+}
+
+__global__ void kh_make_kaiser(float *window, int M, float beta) {
+  float const numc = (float)(M_PI * (double)beta);
+  float const inv_denom = (float)(1. / (double)dev_i0f(numc));
+  float const pc = (float)(2.0 / (double)(M - 1));
+  for (int n = blockIdx.x * blockDim.x + threadIdx.x; n < M; n += gridDim.x * blockDim.x)
+    window[n] = dev_kaiser(n, M, numc, inv_denom, pc);
+}
+int launch_make_kaiser(hipStream_t st, float *window_dev, int M, float beta) {
+  if (M <= 0) return 0;
+  hipLaunchKernelGGL(kh_make_kaiser, dim3((M + 255) / 256), dim3(256), 0, st, window_dev, M, beta);
+  return KH_HIP(hipGetLastError()) ? 0 : -1;
+}
+
+// set_filter's brick wall, filter.c:674-691
+__global__ void kh_brickwall(float2 *resp, int ND, float low, float high, float gain) {
+  for (int n = blockIdx.x * blockDim.x + threadIdx.x; n < ND; n += gridDim.x * blockDim.x) {
+    float f;
+    if (n <= ND / 2)
+      f = (float)n / ND;
+    else
+      f = (float)(n - ND) / ND;
+    resp[n] = (f >= low && f <= high) ? make_float2(gain, 0.f) : make_float2(0.f, 0.f);
+  }
+}
+int launch_brickwall(hipStream_t st, float2 *resp_dev, int ND, float low, float high, float gain) {
+  hipLaunchKernelGGL(kh_brickwall, dim3((ND + 255) / 256), dim3(256), 0, st, resp_dev, ND, low, high, gain);
+  return KH_HIP(hipGetLastError()) ? 0 : -1;
+}
+
+// window_filter (filter.c:509-568) and window_rfilter (573-628): to the time domain, rotate by M/2, Kaiser
+// window, gain 1/N, zero pad, back to the frequency domain.  One workgroup.
+template <int ND, int NT>
+__global__ __launch_bounds__(NT) void kh_window_filter(float2 *resp, int M, float beta, int real_filter,
+                                                       const float2 *__restrict__ tw) {
+  __shared__ __attribute__((aligned(16))) float2 buf[ND];
+  constexpr int PT = ND / NT;
+  int const tid = threadIdx.x;
+  if (real_filter) { // c2r input: ND/2+1 bins, Hermitian extension (filter.c:589-590)
+    for (int p = tid; p <= ND / 2; p += NT) {
+      float2 v = resp[p];
+      if (p == 0 || p == ND / 2)
+        buf[p] = make_float2(v.x, 0.f);
+      else {
+        buf[p] = v;
+        buf[ND - p] = cconj(v);
+      }
+    }
+  } else {
+    for (int n = tid; n < ND; n += NT) buf[n] = resp[n];
+  }
+  __syncthreads();
+  lds_fft<ND, 1, NT, 1, 1, false, +1>(buf, tw, tid);
+  float const numc = (float)(M_PI * (double)beta);
+  float const inv_denom = (float)(1. / (double)dev_i0f(numc));
+  float const pc = (float)(2.0 / (double)(M - 1));
+  float const gain = (float)(1. / (double)ND);
+  float2 v[PT];
+#pragma unroll
+  for (int u = 0; u < PT; u++) {
+    int const n = tid + u * NT;
+    float2 r = make_float2(0.f, 0.f); // zero padding, filter.c:546
+    if (n < M) {
+      // filter.c:543-544 runs n = M-1 .. 0 in place: a source index above n and below M has already
+      // been replaced by its own windowed value when it is read.
+      int const src = (n - M / 2 + ND) % ND;
+      float2 s;
+      if (src > n && src < M) {
+        int const src2 = (src - M / 2 + ND) % ND;
+        float const ws = dev_kaiser(src, M, numc, inv_denom, pc);
+        float2 const o = buf[src2];
+        s = make_float2(o.x * ws * gain, o.y * ws * gain);
+      } else {
+        s = buf[src];
+      }
+      if (real_filter) s.y = 0.f;
+      float const w = dev_kaiser(n, M, numc, inv_denom, pc);
+      r = make_float2(s.x * w * gain, s.y * w * gain);
+    }
+    v[u] = r;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int u = 0; u < PT; u++) buf[tid + u * NT] = v[u];
+  __syncthreads();
+  lds_fft<ND, 1, NT, 1, 1, false, -1>(buf, tw, tid);
+  int const nout = real_filter ? ND / 2 + 1 : ND;
+  for (int n = tid; n < nout; n += NT) resp[n] = buf[n];
+}
+
+template <int ND>
+static int launch_wf(hipStream_t st, float2 *resp, int M, float beta, int real_filter) {
+  constexpr int NT = (ND / 4 < 256) ? ND / 4 : 256;
+  const float2 *tw = twiddle_table(ND);
+  if (!tw) return -1;
+  hipLaunchKernelGGL((kh_window_filter<ND, NT>), dim3(1), dim3(NT), 0, st, resp, M, beta, real_filter, tw);
+  return KH_HIP(hipGetLastError()) ? 0 : -1;
+}
+int launch_window_filter(hipStream_t st, float2 *resp_dev, int L, int M, float beta, int real_filter) {
+  int const ND = L + M - 1;
+  if (M < 1 || M > ND) {
+    set_error("window_filter: bad M %d for N %d", M, ND);
+    return -1;
+  }
+  switch (ND) {
+  case 256: return launch_wf<256>(st, resp_dev, M, beta, real_filter);
+  case 512: return launch_wf<512>(st, resp_dev, M, beta, real_filter);
+  case 1024: return launch_wf<1024>(st, resp_dev, M, beta, real_filter);
+  case 2048: return launch_wf<2048>(st, resp_dev, M, beta, real_filter);
+  case 4096: return launch_wf<4096>(st, resp_dev, M, beta, real_filter);
+  case 8192: return launch_wf<8192>(st, resp_dev, M, beta, real_filter);
+  }
+  set_error("window_filter: FFT size %d unsupported (power of two in [256, 8192] required)", ND);
+  return -1;
+}
+
+// noise_gain, filter.c:631-656: scale * sum |response|^2
+__global__ __launch_bounds__(256) void kh_noise_gain(const float2 *__restrict__ resp, int count, float scale, float *out) {
+  __shared__ float part[256];
+  float s = 0.f;
+  for (int n = threadIdx.x; n < count; n += 256) {
+    float2 const r = resp[n];
+    s += r.x * r.x + r.y * r.y;
+  }
+  part[threadIdx.x] = s;
+  __syncthreads();
+  for (int k = 128; k > 0; k >>= 1) {
+    if (threadIdx.x < k) part[threadIdx.x] += part[threadIdx.x + k];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) *out = scale * part[0];
+}
+int launch_noise_gain(hipStream_t st, const float2 *resp_dev, int count, float scale, float *out_dev) {
+  hipLaunchKernelGGL(kh_noise_gain, dim3(1), dim3(256), 0, st, resp_dev, count, scale, out_dev);
+  return KH_HIP(hipGetLastError()) ? 0 : -1;
+}
+
+// ================================================================ overlap-save history carry (filter.c:230)
+__global__ void kh_carry(const char *__restrict__ src, char *__restrict__ dst, size_t row_stride, size_t bytes) {
+  const char *s = src + (size_t)blockIdx.y * row_stride;
+  char *d = dst + (size_t)blockIdx.y * row_stride;
+  size_t const n4 = bytes / 4;
+  for (size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x; k < n4; k += (size_t)gridDim.x * blockDim.x)
+    reinterpret_cast<float *>(d)[k] = reinterpret_cast<const float *>(s)[k];
+}
+int launch_carry(hipStream_t st, const void *src, void *dst, size_t row_stride_bytes, size_t bytes, int nrows) {
+  if (bytes == 0 || nrows <= 0) return 0;
+  size_t const n4 = bytes / 4;
+  int gx = (int)((n4 + 255) / 256);
+  if (gx > 1024) gx = 1024;
+  hipLaunchKernelGGL(kh_carry, dim3(gx, nrows), dim3(256), 0, st, static_cast<const char *>(src),
+                     static_cast<char *>(dst), row_stride_bytes, bytes);
+  return KH_HIP(hipGetLastError()) ? 0 : -1;
+}
+
+} // namespace kh

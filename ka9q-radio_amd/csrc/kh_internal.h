@@ -1,0 +1,113 @@
+// kh_internal.h -- private declarations shared by the kernels and the host-side C ABI of libka9q_hip.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stddef.h>
+
+#define KH_MAX_SMALL_N 8192 // largest transform done by one workgroup in LDS
+
+namespace kh {
+
+// ---------------------------------------------------------------- errors
+void set_error(const char *fmt, ...);
+bool check_hip(hipError_t e, const char *what);
+#define KH_HIP(call) ::kh::check_hip((call), #call)
+int ensure_init();
+hipStream_t default_stream();
+
+// ---------------------------------------------------------------- twiddle tables (device resident, cached per size)
+// exp(-2 pi i k / n), k < n, computed in double on the host
+const float2 *twiddle_table(int n);
+// four-step twiddle W_N^idx = coarse[idx >> 10] * fine[idx & 1023]
+struct BigTwiddle {
+  const float2 *coarse; // exp(-2 pi i (j<<10) / N), j < max(1, N >> 10)
+  const float2 *fine;   // exp(-2 pi i k / N), k < 1024
+};
+BigTwiddle big_twiddle(int n);
+
+// ---------------------------------------------------------------- per-channel device records
+struct ChanDesc {     // one per channel, read by the filter-output kernel
+  int input;          // index of the input spectrum
+  int rotate;         // filter.c:240
+  int out_type;       // enum filtertype
+  int pad;
+};
+
+struct NcoArgs {      // one oscillator over one launch; phase(i) = phase0 + i*freq + rate*i*(i+1)/2 (cycles)
+  double phase0, freq, rate;
+  int active;         // 0: multiply skipped (phasor identically 1, or osc.freq == 0 for Doppler: radio.c:180)
+  int pad;
+};
+struct IngestDesc {   // one per input
+  NcoArgs doppler, lo2;
+  float gain_factor;
+  int pad;
+};
+
+struct DemodDesc {    // one per channel, read by the demodulator kernels
+  int demod;          // enum kh_demod
+  int flat;
+  float headroom;
+  float fm_gain;      // fm.c:47
+  float dsamprate;    // fm.c:27
+  int pll, square, agc, env, channels;
+  float hangtime, recovery_rate;
+  float out_samprate;
+  float am_hang_samples;    // am.c:80
+  float pll_integrator_gain, pll_prop_gain; // osc.c:77-78
+  int lock_limit;     // linear.c:36
+  double shift_freq;  // cycles per output sample
+};
+
+struct DemodState {   // one per channel, device resident, carried from launch to launch
+  // fm.c:26,32,33
+  float2 fm_state;
+  float fm_lastaudio;
+  int fm_squelch_open;
+  // linear.c
+  int hangcount, lock_count, pll_lock, vco_steps;
+  float pll_integrator, snr, agc_gain;
+  double vco_re, vco_im;       // pll.vco.phasor
+  double vco_freq;             // pll.vco.freq
+  double shift_re, shift_im;   // demod->shift.phasor
+  int shift_steps;
+  // am.c
+  int am_hangcount;
+  float am_dc, am_recovery_per_sample;
+};
+
+// ---------------------------------------------------------------- launchers (kh_kernels.hip)
+// forward transform of `nblocks` overlapping blocks per input.  time: cf32 (or f32 when real_input) stream,
+// block b of input i starts at time + i*in_stride + b*L (elements).  spec: i*spec_in_stride + b*N.
+// tmp: scratch of the same size as spec (only used when N > KH_MAX_SMALL_N).
+int launch_forward_fft(hipStream_t st, const void *time, size_t in_stride, int real_input, float2 *spec, float2 *tmp,
+                       size_t spec_in_stride, int N, int L, int nblocks, int ninputs, hipEvent_t mid_event);
+// bin-select x response x inverse transform.  out: cf32 (or f32 when out_type REAL) at
+// out + ch*out_stride + b*olen.
+int launch_filter_output(hipStream_t st, const float2 *spec, size_t spec_in_stride, int N, int in_real,
+                         const ChanDesc *chans, const float2 *response, int ND, int olen, void *out, size_t out_stride,
+                         int nblocks, int nchan);
+// wire format -> cf32 * gain * Doppler * LO2 and per-block energy (radio.c:136-191)
+int launch_ingest(hipStream_t st, const void *raw, size_t raw_stride_bytes, int payload, float2 *time, size_t time_stride,
+                  const IngestDesc *desc, float *block_energy, int L, int nblocks, int ninputs);
+// radio.c:422-465 + 197-202
+int launch_n0(hipStream_t st, const float2 *spec, size_t spec_in_stride, int N, int samprate, float low, float high,
+              const float *block_energy, int L, float *n0_state, float *acc /*3 floats per (input,block)*/,
+              void *input_status, int nblocks, int ninputs);
+// demodulators + scaleclip
+int launch_demod(hipStream_t st, float2 *baseband, size_t bb_stride, int olen, int nblocks, int nchan,
+                 const DemodDesc *desc, DemodState *state, float *audio, int16_t *pcm, size_t pcm_stride,
+                 int pcm_big_endian, void *status /*kh_status[nchan][max_blocks]*/, int status_stride,
+                 const int *fm_list, int n_fm, const int *lin_list, int n_lin, const int *am_list, int n_am);
+// response design on the device (filter.c:481-568, 573-628, 631-702)
+int launch_make_kaiser(hipStream_t st, float *window_dev, int M, float beta);
+int launch_window_filter(hipStream_t st, float2 *resp_dev, int L, int M, float beta, int real_filter);
+int launch_brickwall(hipStream_t st, float2 *resp_dev, int ND, float low, float high, float gain);
+int launch_noise_gain(hipStream_t st, const float2 *resp_dev, int count, float scale, float *out_dev);
+// decimate.c
+int launch_decimate(hipStream_t st, float *rails, size_t rail_stride, int nrails, int chunk, int log_decimate,
+                    int stage_threshold, void *hb15_states, float *hb3_states);
+// copy count elements of elem_bytes from src to dst for each of n rows (overlap-save history carry, filter.c:230)
+int launch_carry(hipStream_t st, const void *src, void *dst, size_t row_stride_bytes, size_t bytes, int nrows);
+
+} // namespace kh
