@@ -1,0 +1,220 @@
+#!/usr/bin/env python3
+"""bench.py -- throughput of the receive DSP hot path on MI355X (BASELINE.json metric).
+
+One "step" = one kh_bank_execute over T blocks of the configs[1] workload (8 MS/s complex float wideband,
+N = 2^18 overlap-save blocks, 64 NBFM 12.5 kHz channels, D = 256 -> 31.25 kS/s PCM): ingest (convert + LO2
+mix + IF power), forward FFT, compute_n0, 64 x (bin select x response x IFFT), 64 FM demodulators, scaleclip.
+The raw I/Q of the step is resident in HBM before the timed region; nothing crosses PCIe inside it.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+
+N > 1 is launched by torch.distributed.run, one rank per GPU: channels shard disjointly, every GPU recomputes
+the forward FFT of the same stream (SURVEY.md 8(e) option A); there is no data-path collective.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(ROOT, "ka9q-radio_amd"))
+
+FS, L, M, D = 8_000_000, 131072, 131073, 256
+N = L + M - 1
+ND = N // D
+OLEN = L // D
+C = 64
+T = 32
+HBM_PEAK_GBPS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: 8 TB/s spec
+
+
+def channel_plan(rank):
+    """64 channels per GPU on a 12.5 kHz raster; rank r owns k = -32+64r .. 31+64r (contiguous in frequency)."""
+    import synth
+    ks = [k + 64 * rank for k in range(-32, 32)]
+    plan = []
+    for j, k in enumerate(ks):
+        amp = 0.01 * (10.0 ** (j / 63.0))  # 0.01 .. 0.1 log spaced
+        plan.append((k, amp, 300.0 + 50.0 * (j % 64), 2500.0))
+    return plan, [synth.rotate_for(k, 12500.0, N, FS) for k in ks]
+
+
+def make_input_torch(plan, device):
+    """noise + one NBFM carrier per channel, T*L samples, generated on the GPU (setup, not timed)."""
+    import torch
+    g = torch.Generator(device=device)
+    g.manual_seed(0x6B613971)
+    n = T * L
+    x = torch.randn(n, 2, device=device, generator=g, dtype=torch.float32) * 0.01
+    t = torch.arange(n, device=device, dtype=torch.float64) / FS
+    import synth
+    for (k, amp, tone, dev) in plan:
+        fc = synth.rotate_for(k, 12500.0, N, FS) * FS / N
+        ph = 2 * np.pi * fc * t + (dev / tone) * torch.sin(2 * np.pi * tone * t) + 0.1 * k
+        ph = torch.remainder(ph, 2 * np.pi).to(torch.float32)
+        x[:, 0] += amp * torch.cos(ph)
+        x[:, 1] += amp * torch.sin(ph)
+    return x.contiguous()
+
+
+def stage_bytes(bincount):
+    """algorithmic bytes per launch of each stage (DESIGN.md 'Kernels'): what the kernel must read + write."""
+    return {
+        "ingest": T * L * (8 + 8),
+        "fft1": T * 16 * N,
+        "fft2": T * 16 * N,
+        "n0": T * 2 * 8 * bincount,
+        "chan": C * T * (8 * ND + 8 * ND + 8 * OLEN),
+        "demod": C * T * (8 * OLEN + 2 * OLEN),
+        "carry": 2 * 8 * (M - 1),
+    }
+
+
+def cpu_baseline(x_host, rots, budget_s=12.0):
+    """the oracle (kind 'port': the CPU restatement, reference COPTS) on the same workload, single thread,
+    bounded sample.  TEST INFRASTRUCTURE used as a reported baseline only."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import pipeline
+    pipe = pipeline.Pipeline(L, M, D, FS, compute_n0=True, n0_low=-5500.0, n0_high=5500.0, fast=True)
+    for r in rots:
+        pipe.add_channel(demod="fm", rotate=r, low=-5500.0, high=5500.0, kaiser_beta=3.0)
+    nb_avail = x_host.size // L
+    t0 = time.perf_counter()
+    nb = 0
+    while True:  # the sample repeats circularly; the NCO/demodulator state simply runs on
+        k = nb % nb_avail
+        pipe.run_block([x_host[k * L:(k + 1) * L]])
+        nb += 1
+        if time.perf_counter() - t0 > budget_s:
+            break
+    dt = time.perf_counter() - t0
+    return {"value": nb * L / dt / 1e6, "unit": "MS/s", "cores": 1, "kind": "port",
+            "sample": f"{nb} blocks of {L} samples, {C} NBFM channels, {dt:.1f} s of CPU time",
+            "ms_per_block": 1e3 * dt / nb}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
+    args = ap.parse_args()
+
+    import torch
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and world != args.gpus:
+        print(f"bench.py: --gpus {args.gpus} needs torch.distributed.run with {args.gpus} ranks", file=sys.stderr)
+        sys.exit(2)
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=device)
+
+    import pyka9q
+    assert pyka9q.lib().ka9q_hip_init(local_rank) == 0, pyka9q.last_error()
+
+    plan, rots = channel_plan(rank)
+    x = make_input_torch(plan, device)
+    torch.cuda.synchronize()
+
+    bank = pyka9q.Bank(L, M, D, 1, C, T, FS, payload=pyka9q.KH_PT_CF32, compute_n0=1, n0_low=-5500.0, n0_high=5500.0)
+    bank.keep_audio(0)
+    for c, r in enumerate(rots):
+        bank.set_channel(c, demod=pyka9q.KH_DEMOD_FM, rotate=r, low=-5500.0, high=5500.0, kaiser_beta=3.0)
+    bank.write_input_device(0, x.data_ptr(), T * L)  # device -> device; the ring now holds the step's samples
+
+    def step():
+        bank.commit_input(0, T * L)
+        bank.execute(T, sync=False)
+
+    def barrier():
+        bank.sync()
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        tt = torch.tensor([dt], device=device, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+
+    # per-kernel durations: the same K steps with a HIP event pair around every stage on the bank's stream
+    bank.profile(1)
+    for _ in range(args.steps):
+        step()
+    bank.sync()
+    st = bank.stage_times()
+    bank.profile(0)
+
+    # sanity: the run demodulated something (squelch open on the strongest channel)
+    stat = bank.status(C - 1, T)
+    pcm = bank.pcm(C - 1, T)
+    assert stat["squelch_open"].max() > 0 and np.abs(pcm).max() > 100, "bench produced no audio"
+
+    if rank == 0:
+        bincount = N - (int((N * 5500.0) / FS) - int((N * -5500.0) / FS))
+        sb = stage_bytes(bincount)
+        stages = {}
+        for name, (ms, n) in st.items():
+            if n:
+                avg = ms / n
+                stages[name] = {"ms": round(avg, 5), "GBps": round(sb[name] / (avg * 1e-3) / 1e9, 1) if avg > 0 else None}
+        dom = max((k for k in stages if k != "carry"), key=lambda k: stages[k]["ms"])
+        dom_ms = stages[dom]["ms"]
+        achieved = sb[dom] / (dom_ms * 1e-3) / 1e9
+        kernel_name = pyka9q.lib().kh_stage_kernel_name(pyka9q.KH_STAGES.index(dom)).decode()
+        total_alg = T * (16 * N + C * (16 * ND + 2 * OLEN))  # BASELINE.md section 3 formula
+        ms_per_step = 1e3 * dt / args.steps
+        out = {
+            "metric": "aggregate MS/s (input samples consumed per second, all GPUs) on 8 MS/s wideband, 64 NBFM channels per GPU",
+            "value": round(world * args.steps * T * L / dt / 1e6, 2),
+            "unit": "MS/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(ms_per_step, 4),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": "configs[1]: 8 MS/s cf32 wideband, L=131072 M=131073 N=262144, D=256 -> 31.25 kS/s, "
+                                   "64 NBFM 12.5 kHz channels per GPU, 32 blocks (4.19 MS, 0.524 s of signal) per step",
+                       "blocks_per_step": T, "channels_per_gpu": C, "sharding": "channels disjoint per GPU, FFT recomputed per GPU"},
+            "channel_MS_per_s": round(world * C * args.steps * T * L / dt / 1e6, 1),
+            "realtime_factor": round((T * L / FS) / (dt / args.steps), 1),
+            "pipeline_GBps_algorithmic": round(total_alg / (ms_per_step * 1e-3) / 1e9, 1),
+            "stages": stages,
+            "roofline": {"bound": "hbm", "kernel": kernel_name, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS,
+                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": None,
+                         "algorithmic_bytes_per_launch": sb[dom], "avg_launch_ms": dom_ms},
+        }
+        if not args.no_cpu:
+            nb = 6
+            out["cpu_baseline"] = cpu_baseline(x[:nb * L].cpu().numpy().view(np.complex64).reshape(-1), rots)
+        print(json.dumps(out), flush=True)
+    bank.close()
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

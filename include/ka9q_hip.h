@@ -184,7 +184,7 @@ int kh_bank_set_channel(kh_bank *, unsigned int ch, const struct kh_channel_conf
  * cycles/sample^2, phase kept (osc.c:24-27).  The caller applies radio.c:238's negation. */
 int kh_bank_set_lo(kh_bank *, unsigned int input, double lo2_freq, double doppler_freq, double doppler_rate);
 /* proc_samples' per-packet work (radio.c:132-178) as a bulk upload: append `count` samples of wire
- * format cfg.payload to input's raw ring (host pointer).  gain_factor = demod->sdr.gain_factor. */
+ * format cfg.payload to input's raw ring.  `payload` may be a host or a device pointer. */
 int kh_bank_write_input(kh_bank *, unsigned int input, const void *payload, size_t count);
 /* lost samples (radio.c:112-131): append `count` zero samples; the NCOs keep stepping */
 int kh_bank_write_zeros(kh_bank *, unsigned int input, size_t count);
@@ -208,6 +208,8 @@ int kh_bank_read_spectrum(kh_bank *, unsigned int input, unsigned int block, kh_
 int kh_bank_read_response(kh_bank *, unsigned int ch, kh_cf32 *out, float *noise_gain);      /* N_dec bins */
 /* device-resident views for consumers on the GPU */
 int kh_bank_pcm_device_ptr(kh_bank *, void **dptr, size_t *words_per_channel);
+/* 1 (default): also keep the float audio that scaleclip consumed (kh_bank_read_audio); 0: PCM only */
+int kh_bank_keep_audio(kh_bank *, int enable);
 void *kh_bank_stream(kh_bank *); /* hipStream_t */
 /* per-kernel timing with HIP events on the bank's stream.  Stages: */
 enum kh_stage { KH_STAGE_INGEST = 0, KH_STAGE_FFT1, KH_STAGE_FFT2, KH_STAGE_N0, KH_STAGE_CHAN, KH_STAGE_DEMOD,

@@ -321,7 +321,7 @@ int kh_bank_write_input(kh_bank *b, unsigned int input, const void *payload, siz
     return -1;
   }
   unsigned char *dst = b->d_raw + input * b->raw_stride + payload_bytes(b->cfg.payload, b->fill[input]);
-  if (!KH_HIP(hipMemcpyAsync(dst, payload, payload_bytes(b->cfg.payload, count), hipMemcpyHostToDevice, b->stream)))
+  if (!KH_HIP(hipMemcpyAsync(dst, payload, payload_bytes(b->cfg.payload, count), hipMemcpyDefault, b->stream)))
     return -1;
   if (!KH_HIP(hipStreamSynchronize(b->stream))) return -1; // the caller may reuse its buffer
   b->fill[input] += count;
@@ -517,6 +517,11 @@ int kh_bank_pcm_device_ptr(kh_bank *b, void **dptr, size_t *words_per_channel) {
 }
 void *kh_bank_stream(kh_bank *b) { return b ? (void *)b->stream : nullptr; }
 
+int kh_bank_keep_audio(kh_bank *b, int enable) {
+  if (!b) return -1;
+  b->keep_audio = enable != 0;
+  return 0;
+}
 int kh_bank_profile(kh_bank *b, int enable) {
   if (!b) return -1;
   b->profiling = enable != 0;
