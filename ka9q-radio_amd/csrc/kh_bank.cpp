@@ -78,6 +78,10 @@ struct kh_bank {
   kh_input_status *d_istatus = nullptr;
   float *d_energy = nullptr, *d_n0acc = nullptr, *d_n0state = nullptr, *d_scalar = nullptr;
   int *d_lists = nullptr; // fm | linear | am, C entries each
+  void *d_fmstat = nullptr, *d_fmwork = nullptr; // FM path scratch (kh_demod_kernels.hip)
+  double *d_fmcarry = nullptr, *d_decaypow = nullptr;
+  float *d_fmavgf = nullptr;
+  int fm_parity = 0;
   // host
   std::vector<ChanDesc> chans;
   std::vector<DemodDesc> ddesc;
@@ -107,7 +111,8 @@ int kh_bank_destroy(kh_bank *b) {
   if (b->stream) hipStreamSynchronize(b->stream);
   void *ptrs[] = {b->d_raw,   b->d_time[0], b->d_time[1], b->d_spec,   b->d_tmp,    b->d_chans,  b->d_resp,
                   b->d_ddesc, b->d_dstate,  b->d_idesc,   b->d_bb,     b->d_audio,  b->d_pcm,    b->d_status,
-                  b->d_istatus, b->d_energy, b->d_n0acc,  b->d_n0state, b->d_scalar, b->d_lists};
+                  b->d_istatus, b->d_energy, b->d_n0acc,  b->d_n0state, b->d_scalar, b->d_lists,
+                  b->d_fmstat, b->d_fmwork, b->d_fmcarry, b->d_decaypow, b->d_fmavgf};
   for (void *p : ptrs)
     if (p) hipFree(p);
   for (auto &e : b->ev)
@@ -181,13 +186,27 @@ kh_bank *kh_bank_create(const struct kh_bank_config *cfg) {
   A(&b->d_pcm, C * b->pcm_stride * sizeof(int16_t), true);
   A(&b->d_status, C * T * sizeof(kh_status), true);
   A(&b->d_istatus, P * T * sizeof(kh_input_status), true);
-  A(&b->d_energy, P * T * sizeof(float), true);
-  A(&b->d_n0acc, 3 * P * T * sizeof(float), true);
+  A(&b->d_energy, P * T * ingest_chunks(cfg->L) * sizeof(float), true);
+  A(&b->d_n0acc, n0_part_floats() * P * T * sizeof(float), true);
   A(&b->d_n0state, P * sizeof(float), false);
   A(&b->d_scalar, sizeof(float), true);
   A(&b->d_lists, 3 * C * sizeof(int), true);
+  A(&b->d_fmstat, C * T * 16, true);
+  A(&b->d_fmwork, C * b->bb_stride * 8, true);
+  A(&b->d_fmcarry, C * T * sizeof(double), true);
+  A(&b->d_fmavgf, C * T * sizeof(float), true);
+  A(&b->d_decaypow, (b->olen + 1) * sizeof(double), false);
   for (auto &e : b->ev)
     if (ok) ok = KH_HIP(hipEventCreate(&e));
+  if (ok) { // 0.99376949^k (fm.c:111), by repeated multiplication in long double
+    std::vector<double> dp(b->olen + 1);
+    long double v = 1.0L;
+    for (int k = 0; k <= b->olen; k++) {
+      dp[k] = (double)v;
+      v *= 0.99376949L;
+    }
+    ok = KH_HIP(hipMemcpy(b->d_decaypow, dp.data(), dp.size() * sizeof(double), hipMemcpyHostToDevice));
+  }
   if (ok) { // n0 starts as NaN ("Happens at startup", radio.c:199-202)
     std::vector<float> nan(P, NAN);
     ok = KH_HIP(hipMemcpy(b->d_n0state, nan.data(), P * sizeof(float), hipMemcpyHostToDevice));
@@ -254,7 +273,7 @@ int kh_bank_set_channel(kh_bank *b, unsigned int ch, const struct kh_channel_con
   if (!KH_HIP(hipStreamSynchronize(st))) return -1;
   b->noise_gains[ch] = ng;
   b->ccfg[ch] = *c;
-  b->chans[ch] = ChanDesc{(int)c->input, c->rotate, c->out_type, 0};
+  b->chans[ch] = ChanDesc{(int)c->input, c->rotate, c->out_type, c->demod == KH_DEMOD_FM};
   DemodDesc d{};
   d.demod = c->demod;
   d.flat = c->flat;
@@ -295,6 +314,7 @@ int kh_bank_set_channel(kh_bank *b, unsigned int ch, const struct kh_channel_con
     float const samptime = b->cfg.decimate / (float)b->cfg.samprate;
     s.am_recovery_per_sample = powf(10.f, (c->recovery_rate * samptime) / 20.f);
   }
+  // (both FM parity slots start zeroed: fm.c:26,32,33)
   if (!KH_HIP(hipMemcpyAsync(b->d_dstate + ch, &s, sizeof(s), hipMemcpyHostToDevice, st))) return -1;
   if (!KH_HIP(hipStreamSynchronize(st))) return -1;
   b->chans_dirty = true;
@@ -424,13 +444,15 @@ int kh_bank_execute(kh_bank *b, unsigned int nblocks) {
     return -1;
   mark(); // 4
   if (launch_filter_output(st, b->d_spec, b->spec_stride, N, 0, b->d_chans, b->d_resp, b->ND, b->olen, b->d_bb,
-                           b->bb_stride, nblocks, C))
+                           b->bb_stride, nblocks, C, b->d_fmstat, b->T))
     return -1;
   mark(); // 5
   if (launch_demod(st, b->d_bb, b->bb_stride, b->olen, nblocks, C, b->d_ddesc, b->d_dstate,
                    b->keep_audio ? b->d_audio : nullptr, b->d_pcm, b->pcm_stride, b->cfg.pcm_big_endian, b->d_status,
-                   b->T, b->d_lists, b->n_fm, b->d_lists + C, b->n_lin, b->d_lists + 2 * C, b->n_am))
+                   b->T, b->d_lists, b->n_fm, b->d_lists + C, b->n_lin, b->d_lists + 2 * C, b->n_am,
+                   FmScratch{b->d_fmstat, b->d_fmwork, b->d_fmcarry, b->d_fmavgf, b->d_decaypow, b->fm_parity}))
     return -1;
+  if (b->n_fm) b->fm_parity ^= 1;
   mark(); // 6
   // overlap-save history for the next call (filter.c:230), into the other buffer
   if (launch_carry(st, time + need, b->d_time[b->cur ^ 1], b->time_stride * sizeof(float2), (size_t)(M - 1) * sizeof(float2),

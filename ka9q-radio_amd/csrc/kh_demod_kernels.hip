@@ -15,6 +15,7 @@
 // definition and run one LANE per channel, 64 channels in lock-step per wavefront.
 #include "kh_internal.h"
 #include "kh_fft.cuh"
+#include "kh_fm.cuh"
 #include "../../include/ka9q_hip.h"
 
 namespace kh {
@@ -72,11 +73,13 @@ __device__ __forceinline__ float2 load_raw(const unsigned char *raw, size_t n, i
 // algorithmic bytes per sample: wire bytes read + 8 written
 __global__ __launch_bounds__(256) void kh_ingest(const unsigned char *__restrict__ raw, size_t raw_stride_bytes,
                                                  int payload, float2 *__restrict__ time, size_t time_stride,
-                                                 const IngestDesc *__restrict__ descs, float *__restrict__ block_energy,
+                                                 const IngestDesc *__restrict__ descs, float *__restrict__ energy_part,
                                                  int L, int nblocks) {
   __shared__ float part[4];
   int const b = blockIdx.y, i = blockIdx.z;
-  IngestDesc const d = descs[i];
+  const IngestDesc *dp = descs + i;
+  float const gain_factor = dp->gain_factor;
+  int const dop_active = dp->doppler.active, lo_active = dp->lo2.active;
   const unsigned char *src = raw + (size_t)i * raw_stride_bytes;
   float2 *dst = time + (size_t)i * time_stride;
   float energy = 0.f;
@@ -85,17 +88,17 @@ __global__ __launch_bounds__(256) void kh_ingest(const unsigned char *__restrict
     int const k = blockIdx.x * 1024 + u * 256 + threadIdx.x;
     if (k < L) {
       size_t const n = (size_t)b * L + k;
-      float2 x = load_raw(src, n, payload, d.gain_factor);
-      if (d.doppler.active) { // radio.c:180-184: complex float *= complex double
+      float2 x = load_raw(src, n, payload, gain_factor);
+      if (dop_active) { // radio.c:180-184: complex float *= complex double
         double c, s;
-        nco_phasor(d.doppler, (unsigned)n, c, s);
+        nco_phasor(dp->doppler, (unsigned)n, c, s);
         double const re = (double)x.x * c - (double)x.y * s;
         double const im = (double)x.x * s + (double)x.y * c;
         x = make_float2((float)re, (float)im);
       }
-      if (d.lo2.active) { // radio.c:187
+      if (lo_active) { // radio.c:187
         double c, s;
-        nco_phasor(d.lo2, (unsigned)n, c, s);
+        nco_phasor(dp->lo2, (unsigned)n, c, s);
         double const re = (double)x.x * c - (double)x.y * s;
         double const im = (double)x.x * s + (double)x.y * c;
         x = make_float2((float)re, (float)im);
@@ -107,34 +110,46 @@ __global__ __launch_bounds__(256) void kh_ingest(const unsigned char *__restrict
   energy = wave_sum(energy);
   if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = energy;
   __syncthreads();
-  if (threadIdx.x == 0) atomicAdd(&block_energy[i * nblocks + b], part[0] + part[1] + part[2] + part[3]);
+  if (threadIdx.x == 0)
+    energy_part[((size_t)i * nblocks + b) * gridDim.x + blockIdx.x] = part[0] + part[1] + part[2] + part[3];
 }
 
+int ingest_chunks(int L) { return (L + 1023) / 1024; }
+
 int launch_ingest(hipStream_t st, const void *raw, size_t raw_stride_bytes, int payload, float2 *time,
-                  size_t time_stride, const IngestDesc *desc, float *block_energy, int L, int nblocks, int ninputs) {
+                  size_t time_stride, const IngestDesc *desc, float *energy_part, int L, int nblocks, int ninputs) {
   if (nblocks <= 0 || ninputs <= 0) return 0;
-  if (!KH_HIP(hipMemsetAsync(block_energy, 0, sizeof(float) * (size_t)nblocks * ninputs, st))) return -1;
-  hipLaunchKernelGGL(kh_ingest, dim3((L + 1023) / 1024, nblocks, ninputs), dim3(256), 0, st,
+  hipLaunchKernelGGL(kh_ingest, dim3(ingest_chunks(L), nblocks, ninputs), dim3(256), 0, st,
                      static_cast<const unsigned char *>(raw), raw_stride_bytes, payload, time, time_stride, desc,
-                     block_energy, L, nblocks);
+                     energy_part, L, nblocks);
   return KH_HIP(hipGetLastError()) ? 0 : -1;
 }
 
 // ================================================================ compute_n0: radio.c:422-465
 // pass 0: sum of |X|^2 over the bins outside the passband; pass 1: sum and count of those below twice that
-// mean.  acc holds 3 floats per (input, block): {sum0, sum1, count1}.
+// mean.  Every workgroup leaves its partial sums in `part` ([input][block][N0_GX] x {sum0, sum1, count1});
+// kh_n0_final adds them up in a fixed order (no atomics: the result is reproducible run to run).
 // algorithmic bytes: 8*bincount per pass
+constexpr int N0_GX = 64; // workgroups per (input, block)
+
 template <int PASS>
 __global__ __launch_bounds__(256) void kh_n0_pass(const float2 *__restrict__ spec, size_t spec_in_stride, int N,
-                                                  int start, int bincount, float *__restrict__ acc, int nblocks) {
+                                                  int start, int bincount, float *__restrict__ part, int nblocks) {
   __shared__ float ps[4], pc[4];
   int const b = blockIdx.y, i = blockIdx.z;
   const float2 *fd = spec + (size_t)i * spec_in_stride + (size_t)b * N;
-  float *a = acc + 3 * ((size_t)i * nblocks + b);
+  float *a = part + 3 * N0_GX * ((size_t)i * nblocks + b);
   float thresh = INFINITY;
-  if (PASS == 1) thresh = (a[0] / bincount) * 2; // radio.c:456,461
+  if (PASS == 1) { // radio.c:456,461: twice the mean of pass 0
+    float t = threadIdx.x < N0_GX ? a[3 * threadIdx.x] : 0.f;
+    t = wave_sum(t); // N0_GX == 64: all partials sit in wave 0; the other waves add zeros
+    if ((threadIdx.x & 63) == 0) ps[threadIdx.x >> 6] = t;
+    __syncthreads();
+    thresh = (ps[0] / bincount) * 2;
+    __syncthreads();
+  }
   float s = 0.f, c = 0.f;
-  for (int n = blockIdx.x * 256 + threadIdx.x; n < bincount; n += gridDim.x * 256) {
+  for (int n = blockIdx.x * 256 + threadIdx.x; n < bincount; n += N0_GX * 256) {
     int in = start + n; // radio.c:440-446
     if (in >= N) in -= N;
     float2 const x = fd[in];
@@ -153,72 +168,95 @@ __global__ __launch_bounds__(256) void kh_n0_pass(const float2 *__restrict__ spe
   __syncthreads();
   if (threadIdx.x == 0) {
     if (PASS == 0)
-      atomicAdd(&a[0], ps[0] + ps[1] + ps[2] + ps[3]);
+      a[3 * blockIdx.x] = ps[0] + ps[1] + ps[2] + ps[3];
     else {
-      atomicAdd(&a[1], ps[0] + ps[1] + ps[2] + ps[3]);
-      atomicAdd(&a[2], pc[0] + pc[1] + pc[2] + pc[3]);
+      a[3 * blockIdx.x + 1] = ps[0] + ps[1] + ps[2] + ps[3];
+      a[3 * blockIdx.x + 2] = pc[0] + pc[1] + pc[2] + pc[3];
     }
   }
 }
 
-// one thread per input: finish compute_n0 and apply radio.c:197-202 block by block
-__global__ void kh_n0_final(const float *__restrict__ acc, const float *__restrict__ block_energy, int L, int N,
-                            int samprate, int bincount, int valid, float *__restrict__ n0_state,
-                            kh_input_status *__restrict__ status, int nblocks, int ninputs) {
-  int const i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= ninputs) return;
-  float n0 = n0_state[i];
-  for (int b = 0; b < nblocks; b++) {
-    const float *a = acc + 3 * ((size_t)i * nblocks + b);
-    float v = 0.f; // "Can this happen?" radio.c:433-435
-    if (valid) v = (a[1] / a[2]) / ((float)N * samprate);
-    if (!isnan(n0))
-      n0 = (float)((double)n0 + .005 * (double)(v - n0));
-    else
-      n0 = v;
-    status[(size_t)i * nblocks + b].if_power = block_energy[i * nblocks + b] / L;
-    status[(size_t)i * nblocks + b].n0 = n0;
+// one workgroup per input: each wave adds up the partials of a block (fixed order: reproducible), then lane 0
+// applies radio.c:197-202 block by block from LDS
+constexpr int N0_MAXB = 1024; // blocks per launch the smoothing pass can hold
+__global__ __launch_bounds__(256) void kh_n0_final(const float *__restrict__ part, const float *__restrict__ energy_part,
+                                                   int echunks, int L, int N, int samprate, int valid, int have_n0,
+                                                   float *__restrict__ n0_state, kh_input_status *__restrict__ status,
+                                                   int nblocks) {
+  __shared__ float sv[N0_MAXB], se[N0_MAXB];
+  int const i = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int b = wave; b < nblocks; b += 4) {
+    const float *e = energy_part + ((size_t)i * nblocks + b) * echunks;
+    float es = 0.f;
+    for (int k = lane; k < echunks; k += 64) es += e[k];
+    es = wave_sum(es);
+    float v = NAN;
+    if (have_n0) {
+      v = 0.f; // "Can this happen?" radio.c:433-435
+      if (valid) {
+        const float *a = part + 3 * N0_GX * ((size_t)i * nblocks + b);
+        float s1 = wave_sum(a[3 * lane + 1]); // N0_GX == 64 partials, one per lane
+        float c1 = wave_sum(a[3 * lane + 2]);
+        v = (s1 / c1) / ((float)N * samprate); // radio.c:461,464
+      }
+    }
+    if (lane == 0) {
+      se[b] = es / L; // radio.c:197
+      sv[b] = v;
+    }
   }
-  n0_state[i] = n0;
-}
-__global__ void kh_ifpower_only(const float *__restrict__ block_energy, int L, kh_input_status *__restrict__ status,
-                                int total) {
-  int const k = blockIdx.x * blockDim.x + threadIdx.x;
-  if (k >= total) return;
-  status[k].if_power = block_energy[k] / L;
-  status[k].n0 = NAN;
+  __syncthreads();
+  if (threadIdx.x == 0 && have_n0) {
+    float n0 = n0_state[i];
+    for (int b = 0; b < nblocks; b++) {
+      float const v = sv[b];
+      if (!isnan(n0))
+        n0 = (float)((double)n0 + .005 * (double)(v - n0));
+      else
+        n0 = v;
+      sv[b] = n0;
+    }
+    n0_state[i] = n0;
+  }
+  __syncthreads();
+  for (int b = threadIdx.x; b < nblocks; b += 256) {
+    status[(size_t)i * nblocks + b].if_power = se[b];
+    status[(size_t)i * nblocks + b].n0 = sv[b];
+  }
 }
 
+int n0_part_floats() { return 3 * N0_GX; }
+
 int launch_n0(hipStream_t st, const float2 *spec, size_t spec_in_stride, int N, int samprate, float low, float high,
-              const float *block_energy, int L, float *n0_state, float *acc, void *input_status, int nblocks,
+              const float *energy_part, int L, float *n0_state, float *part, void *input_status, int nblocks,
               int ninputs) {
   if (nblocks <= 0 || ninputs <= 0) return 0;
+  if (nblocks > N0_MAXB) {
+    set_error("at most %d blocks per launch", N0_MAXB);
+    return -1;
+  }
   kh_input_status *status = static_cast<kh_input_status *>(input_status);
-  if (spec == nullptr) { // n0 disabled: only if_power
-    int const total = nblocks * ninputs;
-    hipLaunchKernelGGL(kh_ifpower_only, dim3((total + 63) / 64), dim3(64), 0, st, block_energy, L, status, total);
-    return KH_HIP(hipGetLastError()) ? 0 : -1;
+  int const have_n0 = spec != nullptr;
+  int valid = 0;
+  if (have_n0) {
+    int const low_n = (int)((N * low) / samprate); // radio.c:430-431: float arithmetic, truncated
+    int const high_n = (int)((N * high) / samprate);
+    int const bincount = N - (high_n - low_n);
+    valid = !(bincount < 0 || bincount > N) && bincount > 0;
+    int start = high_n + 1;
+    if (start >= N)
+      start -= N;
+    else if (start < 0)
+      start += N;
+    if (valid) {
+      hipLaunchKernelGGL(kh_n0_pass<0>, dim3(N0_GX, nblocks, ninputs), dim3(256), 0, st, spec, spec_in_stride, N, start,
+                         bincount, part, nblocks);
+      hipLaunchKernelGGL(kh_n0_pass<1>, dim3(N0_GX, nblocks, ninputs), dim3(256), 0, st, spec, spec_in_stride, N, start,
+                         bincount, part, nblocks);
+    }
   }
-  int const low_n = (int)((N * low) / samprate); // radio.c:430-431: float arithmetic, truncated
-  int const high_n = (int)((N * high) / samprate);
-  int const bincount = N - (high_n - low_n);
-  int const valid = !(bincount < 0 || bincount > N);
-  int start = high_n + 1;
-  if (start >= N)
-    start -= N;
-  else if (start < 0)
-    start += N;
-  if (!KH_HIP(hipMemsetAsync(acc, 0, sizeof(float) * 3 * (size_t)nblocks * ninputs, st))) return -1;
-  if (valid && bincount > 0) {
-    int gx = (bincount + 4095) / 4096;
-    if (gx < 1) gx = 1;
-    hipLaunchKernelGGL(kh_n0_pass<0>, dim3(gx, nblocks, ninputs), dim3(256), 0, st, spec, spec_in_stride, N, start,
-                       bincount, acc, nblocks);
-    hipLaunchKernelGGL(kh_n0_pass<1>, dim3(gx, nblocks, ninputs), dim3(256), 0, st, spec, spec_in_stride, N, start,
-                       bincount, acc, nblocks);
-  }
-  hipLaunchKernelGGL(kh_n0_final, dim3((ninputs + 63) / 64), dim3(64), 0, st, acc, block_energy, L, N, samprate,
-                     bincount, valid, n0_state, status, nblocks, ninputs);
+  hipLaunchKernelGGL(kh_n0_final, dim3(ninputs), dim3(256), 0, st, part, energy_part, ingest_chunks(L), L, N, samprate,
+                     valid, have_n0, n0_state, status, nblocks);
   return KH_HIP(hipGetLastError()) ? 0 : -1;
 }
 
@@ -235,276 +273,303 @@ __device__ __forceinline__ short pcm_word(float x, int big_endian) {
   return (short)(unsigned short)((u << 8) | (u >> 8)); // htons, audio.c:50,101
 }
 
-// ================================================================ FM: fm.c
-__device__ double fm_i0(double z) { // fm.c:152-163
-  double const t = 0.25 * (z * z);
-  double sum = 1 + t;
-  double term = t;
-  for (int k = 2; k < 40; k++) {
-    term *= t / (k * k);
-    sum += term;
-    if (term < 1e-12 * sum) break;
-  }
-  return sum;
+// ================================================================ FM: fm.c:43-139 in three parallel steps
+//  (1) kh_filter_out's epilogue leaves bb_power, fm_variance and the Rice-corrected SNR of every block
+//      (fm.c:53-70) in FmBlockStat.
+//  (2) kh_fm_disc, one workgroup per (channel, block): squelch decision, conjugate-product discriminator,
+//      threshold-extension weight, and the de-emphasis integrator run from a ZERO carry-in.
+//  (3) kh_fm_finish, one workgroup per (channel, block): folds the carries of the earlier blocks
+//      (s_n = s0_n + carry * decay^k, exact by linearity of fm.c:110-111), scaleclip, output level,
+//      frequency offset and the order-dependent peak-deviation update of fm.c:97-102.
+// The squelch (fm.c:73-78) looks back at most one block (squelch_open = 2 spans two blocks), so every
+// workgroup replays it from the per-block SNRs without talking to its neighbours.
+constexpr int FMB_NT = 256;
+constexpr double FM_DECAY = 0.99376949; // fm.c:111,130
+
+struct FmWork { // per sample, between kh_fm_disc and kh_fm_finish
+  float ang, s0;
+};
+
+// fm.c:73-78 in closed form.  `squelch_open = 2` spans two blocks and is decremented once per open block, so
+// after block j the counter is 1 if snr_j > 4, else max(counter_{j-1} - 1, 0), which is 0 for every j >= 1
+// (counter_{j-1} <= 1) and max(so_in - 1, 0) for j = 0.  Block b demodulates iff snr_b > 4 or the counter
+// before it is positive.  so_in = counter carried in from the previous launch.
+__device__ __forceinline__ int fm_counter_after(const FmBlockStat *__restrict__ fs, int j, int so_in) {
+  if (j < 0) return so_in;
+  if (fs[j].snr > 4.f) return 1;
+  if (j == 0) return so_in - 1 > 0 ? so_in - 1 : 0;
+  return 0;
 }
-__device__ double fm_i1(double z) { // fm.c:166-179
-  double const t = 0.25 * (z * z);
-  double term = 0.5 * t;
-  double sum = 1 + term;
-  for (int k = 2; k < 40; k++) {
-    term *= t / (k * (k + 1));
-    sum += term;
-    if (term < 1e-12 * sum) break;
-  }
-  return 0.5 * z * sum;
-}
-__device__ double fm_xi(double thetasq) { // fm.c:180-186
-  double t = (2 + thetasq) * fm_i0(0.25 * thetasq) + thetasq * fm_i1(0.25 * thetasq);
-  t *= t;
-  return 2 + thetasq - (0.125 * M_PI) * exp(-0.5 * thetasq) * t;
-}
-__device__ double fm_snr(double r) { // fm.c:190-205
-  double thetasq = r;
-  double othetasq = r + 10;
-  if (r <= M_PI / (4 - M_PI)) return 0;
-  if (r > 100) return r;
-  int guard = 0; // the reference loop has no bound; NaN input falls through both tests above and exits here
-  while (fabs(thetasq - othetasq) > .001 && guard++ < 10000) {
-    othetasq = thetasq;
-    thetasq = fm_xi(thetasq) * (1 + r) - 2;
-  }
-  return thetasq;
+__device__ __forceinline__ void fm_squelch(const FmBlockStat *__restrict__ fs, int b, int so_in, int &open_b,
+                                           int &open_prev, int &so_out) {
+  int const before = fm_counter_after(fs, b - 1, so_in);
+  open_b = fs[b].snr > 4.f || before > 0;
+  so_out = fm_counter_after(fs, b, so_in);
+  open_prev = 0;
+  if (b > 0) open_prev = fs[b - 1].snr > 4.f || fm_counter_after(fs, b - 2, so_in) > 0;
 }
 
-constexpr int FM_NT = 512;
-constexpr int FM_MAXS = 8192; // samples per group held in LDS
-constexpr int FM_MAXG = 64;   // blocks per group
-#define FM_SK(n) ((n) + ((n) >> 4))
-
-// one workgroup per FM channel; blocks are processed in groups of G = min(FM_MAXG, FM_MAXS/olen)
-__global__ __launch_bounds__(FM_NT) void kh_demod_fm(const float2 *__restrict__ baseband, size_t bb_stride, int olen,
-                                                     int nblocks, const DemodDesc *__restrict__ descs,
-                                                     DemodState *__restrict__ states, float *__restrict__ audio,
-                                                     int16_t *__restrict__ pcm, size_t pcm_stride, int big_endian,
-                                                     kh_status *__restrict__ status, int status_stride,
-                                                     const int *__restrict__ list) {
-  __shared__ float s_ang[FM_SK(FM_MAXS) + 1];
-  __shared__ float s_aud[FM_SK(FM_MAXS) + 1]; // amplitude, then |p|/var weight, then audio
-  __shared__ float b_bb[FM_MAXG], b_avg[FM_MAXG], b_var[FM_MAXG], b_snr[FM_MAXG], b_lvl[FM_MAXG];
-  __shared__ float b_avgf[FM_MAXG], b_pdev[FM_MAXG], b_carry[FM_MAXG];
-  __shared__ int b_open[FM_MAXG], b_sq[FM_MAXG];
-  __shared__ float2 b_prev[FM_MAXG];
-  __shared__ double t_A[FM_NT], t_B[FM_NT], t_cin[FM_NT];
-  __shared__ float sh_last;
-
+// algorithmic bytes per (channel, block): 8*olen baseband read + 8*olen work written
+__global__ __launch_bounds__(FMB_NT) void kh_fm_disc(const float2 *__restrict__ baseband, size_t bb_stride, int olen,
+                                                     const DemodDesc *__restrict__ descs,
+                                                     const DemodState *__restrict__ states, int par,
+                                                     const FmBlockStat *__restrict__ fmstat, int stat_stride,
+                                                     FmWork *__restrict__ work, double *__restrict__ carry,
+                                                     float *__restrict__ avgf, const int *__restrict__ list) {
+  extern __shared__ __attribute__((aligned(16))) float2 sm[]; // y (olen+1 entries, y[-1] first), then (ang, s0)
+  __shared__ double w_A[FMB_NT / 64], w_B[FMB_NT / 64];
+  __shared__ float red[FMB_NT / 64];
   int const tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  int const ch = list[blockIdx.x];
-  DemodDesc const d = descs[ch];
-  DemodState *st = &states[ch];
-  const float2 *y = baseband + (size_t)ch * bb_stride;
-  float const gain = d.fm_gain;
-  double const decay = 0.99376949; // fm.c:111,130
-
-  int G = FM_MAXS / olen;
-  if (G > FM_MAXG) G = FM_MAXG;
-  if (G < 1) G = 1; // guarded by the launcher: olen <= FM_MAXS
-
-  float2 state = st->fm_state;
-  float lastaudio = st->fm_lastaudio;
-  int squelch_open = st->fm_squelch_open;
-
-  for (int g0 = 0; g0 < nblocks; g0 += G) {
-    int const gb = (nblocks - g0 < G) ? nblocks - g0 : G;
-    int const ns = gb * olen;
-    const float2 *yg = y + (size_t)g0 * olen;
-
-    // ---- amplitude statistics, fm.c:53-67: one wave per block
-    for (int b = wave; b < gb; b += FM_NT / 64) {
-      float bb = 0.f, sa = 0.f;
-      for (int n = lane; n < olen; n += 64) {
-        float2 const v = yg[b * olen + n];
-        float const t = v.x * v.x + v.y * v.y;
-        float const a = sqrtf(t);
-        s_aud[FM_SK(b * olen + n)] = a;
-        bb += t;
-        sa += a;
-      }
-      bb = wave_sum(bb);
-      sa = wave_sum(sa);
-      float const avg = sa / olen;
-      float var = 0.f;
-      for (int n = lane; n < olen; n += 64) {
-        float const a = s_aud[FM_SK(b * olen + n)];
-        var += (a - avg) * (a - avg);
-      }
-      var = wave_sum(var) / (olen - 1);
-      if (lane == 0) {
-        b_bb[b] = bb / olen;
-        b_avg[b] = avg;
-        b_var[b] = var;
-      }
-    }
-    __syncthreads();
-    // ---- Rice-corrected SNR, fm.c:69-70: one lane per block
-    if (tid < gb) {
-      float const avg = b_avg[tid];
-      float snr = (float)fm_snr((double)(avg * avg / b_var[tid]));
-      b_snr[tid] = fmaxf(0.0f, snr);
-    }
-    __syncthreads();
-    // ---- squelch, fm.c:73-78,123: serial over blocks
+  int const ch = list[blockIdx.x], b = blockIdx.y;
+  const DemodDesc *dd = descs + ch;
+  const DemodState *st = states + ch;
+  const FmBlockStat *fs = fmstat + (size_t)ch * stat_stride;
+  int open, open_prev, so;
+  fm_squelch(fs, b, st->fm_squelch_open[par], open, open_prev, so); // uniform: every lane evaluates it
+  const float2 *y = baseband + (size_t)ch * bb_stride + (size_t)b * olen;
+  FmWork *wo = work + (size_t)ch * bb_stride + (size_t)b * olen;
+  int const flat = dd->flat;
+  float const gain = dd->fm_gain;
+  float const var = fs[b].variance;
+  // stage the block, preceded by `state` on entry (fm.c:86-87,123)
+  if (open) {
+    for (int n = tid; n < olen; n += FMB_NT) sm[n + 1] = y[n];
     if (tid == 0) {
-      float2 prev = state;
-      for (int b = 0; b < gb; b++) {
-        if (b_snr[b] > 4.f) squelch_open = 2;
-        int open = 0;
-        if (squelch_open > 0) {
-          squelch_open--;
-          open = 1;
-        }
-        b_open[b] = open;
-        b_sq[b] = squelch_open;
-        b_prev[b] = prev; // `state` on entry to the block
-        prev = open ? yg[b * olen + olen - 1] : make_float2(0.f, 0.f);
-      }
-      state = prev;
+      if (b == 0)
+        sm[0] = st->fm_state[par];
+      else
+        sm[0] = open_prev ? y[-1] : make_float2(0.f, 0.f);
     }
-    __syncthreads();
-    // ---- discriminator, fm.c:85-93
-    for (int n = tid; n < ns; n += FM_NT) {
-      int const b = n / olen, k = n - b * olen;
+  }
+  __syncthreads();
+  // discriminator in place: sample n reads y_n (slot n+1) and y_{n-1} (slot n) and leaves (ang, weight) in
+  // slot n+1.  Batches of 256 samples run from the top down and read before anyone writes, so a slot is
+  // overwritten only after both of its readers are done.
+  float angsum = 0.f;
+  if (open) {
+    int const nbatch = (olen + FMB_NT - 1) / FMB_NT;
+#pragma unroll 1
+    for (int j = nbatch - 1; j >= 0; j--) {
+      int const n = tid + j * FMB_NT;
       float ang = 0.f, amp = 0.f;
-      if (b_open[b]) {
-        float2 const cur = yg[n];
-        float2 const prev = (k == 0) ? b_prev[b] : yg[n - 1];
-        float2 const p = cmulc(cur, prev);
-        ang = atan2f(p.y, p.x);     // cargf
-        amp = hypotf(p.x, p.y) / b_var[b]; // cabsf(p) / fm_variance
+      if (n < olen) {
+        float2 const p = cmulc(sm[n + 1], sm[n]);
+        ang = atan2f(p.y, p.x);        // cargf, fm.c:89
+        amp = hypotf(p.x, p.y) / var;  // cabsf(p) / fm_variance, fm.c:91
         if (amp > 1) amp = 1;
+        angsum += ang;
       }
-      s_ang[FM_SK(n)] = ang;
-      s_aud[FM_SK(n)] = amp;
+      __syncthreads();
+      if (n < olen) sm[n + 1] = make_float2(ang, amp);
+      __syncthreads();
     }
-    __syncthreads();
-    // ---- de-emphasis integrator, fm.c:104-112,124-132.  s_n = c_{n-1} + x_n ; c_n = s_n * decay, a linear
-    // recurrence: per-thread chunk maps composed serially by one lane, then each chunk replayed from its
-    // carry-in with the reference's float roundings.
-    int const CH = (ns + FM_NT - 1) / FM_NT;
-    int const n0 = tid * CH;
-    int const n1 = (n0 + CH < ns) ? n0 + CH : ns;
-    if (!d.flat) {
-      double A = 1.0, B = 0.0;
+  }
+  // de-emphasis integrator from a zero carry-in: contiguous chunk per thread, affine maps scanned over the block
+  int const CH = (olen + FMB_NT - 1) / FMB_NT;
+  int const n0 = tid * CH;
+  int const n1 = (n0 + CH < olen) ? n0 + CH : olen;
+  double A = 1.0, B = 0.0; // this chunk's map carry_out = A*carry_in + B
+  if (!flat) {
+    if (open) {
       for (int n = n0; n < n1; n++) {
-        int const b = n / olen;
-        double x = 0.0;
-        if (b_open[b]) x = (double)s_ang[FM_SK(n)] * .114 * (double)gain * (double)s_aud[FM_SK(n)];
-        B = (B + x) * decay;
-        A *= decay;
+        float2 const aw = sm[n + 1];
+        double const x = (double)aw.x * .114 * (double)gain * (double)aw.y; // fm.c:110
+        B = (B + x) * FM_DECAY;
+        A *= FM_DECAY;
       }
-      t_A[tid] = A;
-      t_B[tid] = B;
-      __syncthreads();
-      if (tid == 0) {
-        double c = (double)lastaudio;
-        for (int t = 0; t < FM_NT; t++) {
-          t_cin[t] = c;
-          c = t_A[t] * c + t_B[t];
-        }
-      }
-      __syncthreads();
-      float c = (float)t_cin[tid];
-      for (int n = n0; n < n1; n++) {
-        int const b = n / olen;
-        if (n - b * olen == 0) b_carry[b] = c; // lastaudio on entry to the block
-        float s;
-        if (b_open[b]) {
-          double const x = (double)s_ang[FM_SK(n)] * .114 * (double)gain * (double)s_aud[FM_SK(n)];
-          s = (float)((double)c + x); // samples[n] = lastaudio += ...
-        } else {
-          s = c; // samples[n] = lastaudio
-        }
-        c = (float)((double)s * decay);
-        s_aud[FM_SK(n)] = s;
-      }
-      if (n1 == ns && n0 < ns) sh_last = c;
     } else {
-      for (int n = n0; n < n1; n++) {
-        int const b = n / olen;
-        if (n - b * olen == 0) b_carry[b] = lastaudio;
-        s_aud[FM_SK(n)] = b_open[b] ? s_ang[FM_SK(n)] * gain : 0.f; // fm.c:105,126
-      }
-      if (tid == 0) sh_last = lastaudio;
+      for (int n = n0; n < n1; n++) A *= FM_DECAY; // fm.c:130
     }
-    __syncthreads();
-    lastaudio = sh_last;
-    // ---- frequency offset and peak deviation, fm.c:81-83,96-102,114-121: serial per block, one lane per block
-    if (tid < gb && b_open[tid]) {
-      int const b = tid;
-      float pdev_pos = 0, pdev_neg = 0, avg_f = 0;
-      float la = b_carry[b];
-      for (int k = 0; k < olen; k++) {
-        float const ang = s_ang[FM_SK(b * olen + k)];
-        avg_f += ang;
-        if (k == 0)
-          pdev_pos = pdev_neg = ang;
-        else if (ang > pdev_pos)
-          pdev_pos = ang;
-        else if (la < pdev_neg)
-          pdev_neg = ang;
-        if (!d.flat) la = (float)((double)s_aud[FM_SK(b * olen + k)] * decay);
+  }
+  double Ai = A, Bi = B;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    double const Ap = __shfl_up(Ai, o, 64), Bp = __shfl_up(Bi, o, 64);
+    if (lane >= o) {
+      Bi = Ai * Bp + Bi;
+      Ai = Ai * Ap;
+    }
+  }
+  if (lane == 63) {
+    w_A[wave] = Ai;
+    w_B[wave] = Bi;
+  }
+  __syncthreads();
+  double c = 0.0; // zero carry-in at the block start
+  for (int w = 0; w < wave; w++) c = w_A[w] * c + w_B[w];
+  double const Ae = __shfl_up(Ai, 1, 64), Be = __shfl_up(Bi, 1, 64);
+  double cin = lane == 0 ? c : Ae * c + Be; // carry into this thread's chunk
+  if (tid == FMB_NT - 1) carry[(size_t)ch * stat_stride + b] = Ai * c + Bi; // block's carry-out for carry-in 0
+  if (open) {
+    for (int n = n0; n < n1; n++) {
+      float2 const aw = sm[n + 1];
+      float s0;
+      if (flat) {
+        s0 = aw.x * gain; // fm.c:105
+      } else {
+        double const x = (double)aw.x * .114 * (double)gain * (double)aw.y;
+        cin += x;          // samples[n] = lastaudio += ...
+        s0 = (float)cin;
+        cin *= FM_DECAY;   // lastaudio *= 0.99376949
       }
-      avg_f /= olen;
-      b_avgf[b] = d.dsamprate * avg_f * (float)(0.5 * M_1_PI);
+      sm[n + 1] = make_float2(aw.x, s0);
+    }
+  }
+  __syncthreads();
+  for (int n = tid; n < olen; n += FMB_NT) {
+    float2 const v = open ? sm[n + 1] : make_float2(0.f, 0.f); // closed: audio is the decaying carry alone (fm.c:124-132)
+    wo[n] = FmWork{v.x, v.y};
+  }
+  float const tot = block_sum<FMB_NT>(angsum, red);
+  if (tid == 0) avgf[(size_t)ch * stat_stride + b] = tot / olen; // fm.c:96,114
+}
+
+// algorithmic bytes per (channel, block): 8*olen work read + 2*olen PCM written
+__global__ __launch_bounds__(FMB_NT) void kh_fm_finish(const float2 *__restrict__ baseband, size_t bb_stride, int olen,
+                                                       int nblocks, const DemodDesc *__restrict__ descs,
+                                                       DemodState *__restrict__ states, int par,
+                                                       const FmBlockStat *__restrict__ fmstat, int stat_stride,
+                                                       const FmWork *__restrict__ work,
+                                                       const double *__restrict__ carry,
+                                                       const float *__restrict__ avgf,
+                                                       const double *__restrict__ decay_pow,
+                                                       float *__restrict__ audio, int16_t *__restrict__ pcm,
+                                                       size_t pcm_stride, int big_endian, kh_status *__restrict__ status,
+                                                       int status_stride, const int *__restrict__ list) {
+  extern __shared__ __attribute__((aligned(16))) float2 al[]; // (ang, lastaudio seen by the sample), olen entries
+  __shared__ double sh_c;
+  __shared__ float red[FMB_NT / 64];
+  int const tid = threadIdx.x;
+  int const ch = list[blockIdx.x], b = blockIdx.y;
+  const DemodDesc *dd = descs + ch;
+  DemodState *st = states + ch;
+  const FmBlockStat *fs = fmstat + (size_t)ch * stat_stride;
+  int const flat = dd->flat;
+  float const dsamprate = dd->dsamprate;
+  int open, open_prev, so;
+  fm_squelch(fs, b, st->fm_squelch_open[par], open, open_prev, so);
+  float const lastaudio_in = st->fm_lastaudio[par];
+  if (tid < 64) {
+    // lastaudio on entry to this block: the carried value and the zero-carry outputs of the earlier blocks,
+    // each decayed over the blocks in between (fm.c:110-111,130): c = A^b c0 + sum_j A^(b-1-j) B_j
+    double acc = 0.0;
+    if (!flat) {
+      double const Ablk = decay_pow[olen];
+      const double *cb = carry + (size_t)ch * stat_stride;
+      for (int j = tid - 1; j < b; j += 64) { // j = -1 stands for the carried lastaudio
+        double const v = j < 0 ? (double)lastaudio_in : cb[j];
+        int m = b - 1 - j; // blocks to decay over
+        double p = 1.0, q = Ablk;
+        while (m) {
+          if (m & 1) p *= q;
+          q *= q;
+          m >>= 1;
+        }
+        acc += v * p;
+      }
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
+    } else {
+      acc = (double)lastaudio_in;
+    }
+    if (tid == 0) sh_c = acc;
+  }
+  __syncthreads();
+  double const c_in = sh_c;
+  const FmWork *wi = work + (size_t)ch * bb_stride + (size_t)b * olen;
+  size_t const obase = (size_t)b * olen;
+  float *ao = audio ? audio + (size_t)ch * pcm_stride + obase : nullptr;
+  int16_t *po = pcm + (size_t)ch * pcm_stride + obase;
+  float lv = 0.f;
+  for (int n = tid; n < olen; n += FMB_NT) {
+    FmWork const w = wi[n];
+    float s1, la;
+    if (flat) {
+      s1 = w.s0;
+      la = (float)c_in; // lastaudio never changes in flat mode
+    } else {
+      s1 = (float)((double)w.s0 + c_in * decay_pow[n]);
+      la = 0.f;
+      if (n > 0) { // lastaudio when sample n is processed = previous sample * decay (fm.c:110-111)
+        float const sp = (float)((double)wi[n - 1].s0 + c_in * decay_pow[n - 1]);
+        la = (float)((double)sp * FM_DECAY);
+      }
+    }
+    lv += s1 * s1;
+    if (ao) ao[n] = s1;
+    po[n] = pcm_word(s1, big_endian);
+    al[n] = make_float2(w.ang, la);
+  }
+  float const level = block_sum<FMB_NT>(lv, red) / olen; // fm.c:135-138 (its barriers also publish al[])
+  if (tid >= 64) return;
+  // ---- wave 0: status record; fm.c:81-83,97-102's order-dependent peak-deviation update.
+  // pdev_pos is a running maximum (prefix max over lanes); pdev_neg moves to ang_k at the first later sample
+  // that is not a new maximum and whose lastaudio is below the current pdev_neg: a find-first over the
+  // window, repeated from the hit with the new value.  Same result as the serial loop, sample for sample.
+  int const lane = tid;
+  float pdev_pos = 0.f, pdev_neg = 0.f;
+  if (open) {
+    float runmax = -INFINITY;
+    for (int w0 = 0; w0 < olen; w0 += 64) {
+      int const k = w0 + lane;
+      float2 const v = k < olen ? al[k] : make_float2(-INFINITY, INFINITY);
+      // exclusive prefix maximum of ang over the block so far
+      float inc = v.x;
+#pragma unroll
+      for (int o = 1; o < 64; o <<= 1) {
+        float const p = __shfl_up(inc, o, 64);
+        if (lane >= o) inc = fmaxf(inc, p);
+      }
+      float exc = __shfl_up(inc, 1, 64);
+      exc = lane == 0 ? runmax : fmaxf(exc, runmax);
+      bool const up = v.x > exc;          // fm.c:99: ang > pdev_pos
+      float thr = up ? INFINITY : v.y;    // fm.c:101 is only reached when not a new maximum
+      if (k == 0) {                       // fm.c:97-98
+        thr = INFINITY;
+        pdev_neg = v.x;
+      }
+      if (w0 == 0) pdev_neg = __shfl(pdev_neg, 0, 64);
+      unsigned long long live = ~0ull;
+      while (true) {
+        unsigned long long const hit = __ballot(thr < pdev_neg) & live;
+        if (!hit) break;
+        int const i = __ffsll((long long)hit) - 1;
+        pdev_neg = __shfl(v.x, i, 64);    // fm.c:102
+        live = i == 63 ? 0ull : (~0ull << (i + 1));
+      }
+      runmax = fmaxf(runmax, __shfl(inc, 63, 64));
+    }
+    pdev_pos = runmax;
+  }
+  if (lane == 0) {
+    kh_status r;
+    r.bb_power = fs[b].bb_power;
+    r.snr = fs[b].snr;
+    r.foffset = NAN; // fm.c:116,121 leave both untouched while the squelch is closed
+    r.pdeviation = NAN;
+    if (open) {
+      float const avg_f = avgf[(size_t)ch * stat_stride + b];
+      r.foffset = (float)((double)(dsamprate * avg_f) * (0.5 * M_1_PI)); // fm.c:116
       pdev_pos -= avg_f;
       pdev_neg -= avg_f;
-      b_pdev[b] = d.dsamprate * fmaxf(pdev_pos, -pdev_neg) * (float)(0.5 * M_1_PI);
+      r.pdeviation = (float)((double)(dsamprate * fmaxf(pdev_pos, -pdev_neg)) * (0.5 * M_1_PI)); // fm.c:121
     }
-    // ---- output level (fm.c:135-138), audio and PCM out
-    for (int b = wave; b < gb; b += FM_NT / 64) {
-      float lv = 0.f;
-      for (int n = lane; n < olen; n += 64) {
-        float const s = s_aud[FM_SK(b * olen + n)];
-        lv += s * s;
-      }
-      lv = wave_sum(lv);
-      if (lane == 0) b_lvl[b] = lv / olen;
+    r.cphase = 0.f;
+    r.lock_timer = 0.f;
+    r.pll_lock = 0;
+    r.output_level = level;
+    r.agc_gain = NAN;
+    r.squelch_open = so;
+    r.reserved[0] = r.reserved[1] = 0.f;
+    status[(size_t)ch * status_stride + b] = r;
+    if (b == nblocks - 1) { // state carried to the next launch (fm.c:26,32,33)
+      double c = c_in;
+      if (!flat) c = decay_pow[olen] * c + carry[(size_t)ch * stat_stride + b];
+      // written to the other parity slot: workgroups of this launch may still be reading the current one
+      st->fm_lastaudio[par ^ 1] = (float)c;
+      st->fm_squelch_open[par ^ 1] = so;
+      st->fm_state[par ^ 1] = open ? baseband[(size_t)ch * bb_stride + obase + olen - 1] : make_float2(0.f, 0.f);
     }
-    size_t const obase = (size_t)g0 * olen;
-    if (audio) {
-      float *ao = audio + (size_t)ch * pcm_stride + obase;
-      for (int n = tid; n < ns; n += FM_NT) ao[n] = s_aud[FM_SK(n)];
-    }
-    int16_t *po = pcm + (size_t)ch * pcm_stride + obase;
-    for (int n = tid; n < ns; n += FM_NT) po[n] = pcm_word(s_aud[FM_SK(n)], big_endian);
-    __syncthreads();
-    if (tid < gb) {
-      kh_status *so = status + (size_t)ch * status_stride + g0 + tid;
-      kh_status r;
-      r.bb_power = b_bb[tid];
-      r.snr = b_snr[tid];
-      // foffset / pdeviation keep their previous values while the squelch is closed (fm.c:116,121)
-      if (b_open[tid]) {
-        r.foffset = b_avgf[tid];
-        r.pdeviation = b_pdev[tid];
-      } else {
-        r.foffset = NAN;
-        r.pdeviation = NAN;
-      }
-      r.cphase = 0.f;
-      r.lock_timer = 0.f;
-      r.pll_lock = 0;
-      r.output_level = b_lvl[tid];
-      r.agc_gain = NAN;
-      r.squelch_open = b_sq[tid];
-      r.reserved[0] = r.reserved[1] = 0.f;
-      *so = r;
-    }
-    __syncthreads();
-  }
-  if (tid == 0) {
-    st->fm_state = state;
-    st->fm_lastaudio = lastaudio;
-    st->fm_squelch_open = squelch_open;
   }
 }
 
@@ -734,17 +799,23 @@ __global__ __launch_bounds__(64) void kh_demod_am(const float2 *__restrict__ bas
 int launch_demod(hipStream_t st, float2 *baseband, size_t bb_stride, int olen, int nblocks, int nchan,
                  const DemodDesc *desc, DemodState *state, float *audio, int16_t *pcm, size_t pcm_stride,
                  int pcm_big_endian, void *status, int status_stride, const int *fm_list, int n_fm, const int *lin_list,
-                 int n_lin, const int *am_list, int n_am) {
+                 int n_lin, const int *am_list, int n_am, const FmScratch &fm) {
   (void)nchan;
   if (nblocks <= 0) return 0;
   kh_status *stt = static_cast<kh_status *>(status);
   if (n_fm > 0) {
-    if (olen > FM_MAXS || olen < 2) {
-      set_error("FM demodulator: olen %d outside [2, %d]", olen, FM_MAXS);
+    if (olen < 2 || olen > 8192 - 1) {
+      set_error("FM demodulator: olen %d outside [2, 8192]", olen);
       return -1;
     }
-    hipLaunchKernelGGL(kh_demod_fm, dim3(n_fm), dim3(FM_NT), 0, st, baseband, bb_stride, olen, nblocks, desc, state,
-                       audio, pcm, pcm_stride, pcm_big_endian, stt, status_stride, fm_list);
+    const FmBlockStat *fs = static_cast<const FmBlockStat *>(fm.stat);
+    FmWork *wk = static_cast<FmWork *>(fm.work);
+    hipLaunchKernelGGL(kh_fm_disc, dim3(n_fm, nblocks), dim3(FMB_NT), (olen + 1) * sizeof(float2), st, baseband, bb_stride, olen, desc, state, fm.parity,
+                       fs, status_stride, wk, fm.carry, fm.avgf, fm_list);
+    // kh_fm_finish reads the state kh_fm_disc read and then overwrites it: same stream, so ordered
+    hipLaunchKernelGGL(kh_fm_finish, dim3(n_fm, nblocks), dim3(FMB_NT), olen * sizeof(float2), st, baseband, bb_stride,
+                       olen, nblocks, desc, state, fm.parity, fs, status_stride, wk, fm.carry, fm.avgf, fm.decay_pow, audio, pcm,
+                       pcm_stride, pcm_big_endian, stt, status_stride, fm_list);
   }
   if (n_lin > 0)
     hipLaunchKernelGGL(kh_demod_linear, dim3((n_lin + 63) / 64), dim3(64), 0, st, baseband, bb_stride, olen, nblocks,

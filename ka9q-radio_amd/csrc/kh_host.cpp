@@ -386,9 +386,10 @@ int execute_filter_output(struct filter_out *slave, int rotate) {
   o->chan->input = 0;
   o->chan->rotate = rotate;
   o->chan->out_type = out_type;
+  o->chan->fm_stats = 0;
   if (!rc)
     rc = launch_filter_output(o->stream, im->d_spec[blk & 1], 0, o->N, master->in_type == REAL, o->chan,
-                              o->d_resp[o->active], o->ND, o->olen, o->d_out, 0, 1, 1);
+                              o->d_resp[o->active], o->ND, o->olen, o->d_out, 0, 1, 1, nullptr, 0);
   if (!rc) {
     if (out_type == REAL)
       rc = KH_HIP(hipMemcpyAsync(slave->output.r, o->d_out, o->olen * sizeof(float), hipMemcpyDeviceToHost, o->stream))

@@ -30,7 +30,16 @@ struct ChanDesc {     // one per channel, read by the filter-output kernel
   int input;          // index of the input spectrum
   int rotate;         // filter.c:240
   int out_type;       // enum filtertype
-  int pad;
+  int fm_stats;       // 1: the epilogue leaves fm.c:53-70's block statistics for the FM kernels
+};
+
+struct FmScratch {    // device scratch of the FM path (see kh_demod_kernels.hip)
+  void *stat;         // FmBlockStat[nchan][status_stride], written by kh_filter_out
+  void *work;         // FmWork[nchan][bb_stride]
+  double *carry;      // [nchan][status_stride]
+  float *avgf;        // [nchan][status_stride]
+  const double *decay_pow; // 0.99376949^k, k <= olen
+  int parity;         // which DemodState FM slot this launch reads
 };
 
 struct NcoArgs {      // one oscillator over one launch; phase(i) = phase0 + i*freq + rate*i*(i+1)/2 (cycles)
@@ -60,10 +69,10 @@ struct DemodDesc {    // one per channel, read by the demodulator kernels
 };
 
 struct DemodState {   // one per channel, device resident, carried from launch to launch
-  // fm.c:26,32,33
-  float2 fm_state;
-  float fm_lastaudio;
-  int fm_squelch_open;
+  // fm.c:26,32,33; two slots: a launch reads slot `parity` and leaves the next launch's state in the other
+  float2 fm_state[2];
+  float fm_lastaudio[2];
+  int fm_squelch_open[2];
   // linear.c
   int hangcount, lock_count, pll_lock, vco_steps;
   float pll_integrator, snr, agc_gain;
@@ -86,19 +95,24 @@ int launch_forward_fft(hipStream_t st, const void *time, size_t in_stride, int r
 // out + ch*out_stride + b*olen.
 int launch_filter_output(hipStream_t st, const float2 *spec, size_t spec_in_stride, int N, int in_real,
                          const ChanDesc *chans, const float2 *response, int ND, int olen, void *out, size_t out_stride,
-                         int nblocks, int nchan);
+                         int nblocks, int nchan, void *fm_stat /*FmBlockStat[nchan][stat_stride] or null*/,
+                         int stat_stride);
 // wire format -> cf32 * gain * Doppler * LO2 and per-block energy (radio.c:136-191)
+// energy_part: ingest_chunks(L) floats per (input, block), summed by launch_n0
+int ingest_chunks(int L);
+int n0_part_floats();
 int launch_ingest(hipStream_t st, const void *raw, size_t raw_stride_bytes, int payload, float2 *time, size_t time_stride,
-                  const IngestDesc *desc, float *block_energy, int L, int nblocks, int ninputs);
+                  const IngestDesc *desc, float *energy_part, int L, int nblocks, int ninputs);
 // radio.c:422-465 + 197-202
 int launch_n0(hipStream_t st, const float2 *spec, size_t spec_in_stride, int N, int samprate, float low, float high,
-              const float *block_energy, int L, float *n0_state, float *acc /*3 floats per (input,block)*/,
+              const float *energy_part, int L, float *n0_state, float *part /*n0_part_floats() per (input,block)*/,
               void *input_status, int nblocks, int ninputs);
 // demodulators + scaleclip
 int launch_demod(hipStream_t st, float2 *baseband, size_t bb_stride, int olen, int nblocks, int nchan,
                  const DemodDesc *desc, DemodState *state, float *audio, int16_t *pcm, size_t pcm_stride,
                  int pcm_big_endian, void *status /*kh_status[nchan][max_blocks]*/, int status_stride,
-                 const int *fm_list, int n_fm, const int *lin_list, int n_lin, const int *am_list, int n_am);
+                 const int *fm_list, int n_fm, const int *lin_list, int n_lin, const int *am_list, int n_am,
+                 const FmScratch &fm);
 // response design on the device (filter.c:481-568, 573-628, 631-702)
 int launch_make_kaiser(hipStream_t st, float *window_dev, int M, float beta);
 int launch_window_filter(hipStream_t st, float2 *resp_dev, int L, int M, float beta, int real_filter);

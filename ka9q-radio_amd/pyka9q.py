@@ -10,7 +10,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libka9q_hip.so")
+LIB_PATH = os.environ.get("KA9Q_HIP_LIB", os.path.join(_HERE, "libka9q_hip.so"))  # override: diagnostic builds only
 
 NONE, COMPLEX, CROSS_CONJ, REAL = 0, 1, 2, 3
 KH_DEMOD_NONE, KH_DEMOD_FM, KH_DEMOD_LINEAR, KH_DEMOD_AM = 0, 1, 2, 3
