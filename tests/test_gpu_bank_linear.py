@@ -1,0 +1,134 @@
+"""GPU parity: linear.c (SSB/CW/IQ/ISB/DSB/coherent AM/envelope AM) and am.c demodulators in the bank against
+the oracle pipeline.  These demodulators are per-sample recurrences (PLL, hang AGC, DC tracker): the GPU runs one
+lane per channel and must carry the state across blocks and across launches exactly as the reference threads do.
+
+Bars: baseband <= 1e-5 relative RMS (before the PLL rewrites it, linear.c:91), PCM within +-1 LSB,
+status scalars within 1e-4 relative (1e-2 for the PLL's signal/noise ratio, a quotient of two sums whose
+denominator is a small residual)."""
+import os
+
+import numpy as np
+import pytest
+
+import orc
+import pipeline
+import synth
+from conftest import rel_rms
+
+pytestmark = pytest.mark.gpu
+
+FS, L, M, D = 192_000, 3840, 4353, 4
+OLEN = L // D
+HEADROOM = 10 ** (-15 / 20)          # main.c:137
+RECOVERY = 10 ** ((6.0 / 48000) / 20)  # radio.c:398: 6 dB/s at 48 kHz
+AGC0 = 10 ** (80 / 20)               # main.c:139
+PLL_SETTLE = 8  # blocks before the PLL modes are held to the strict bars (see the comment in the test)
+
+
+def _signal(kind, n):
+    noise = synth.noise(n, 0.001, 11)
+    if kind == "usb":
+        return noise + synth.usb_two_tone(0, n, FS, 0.0, 0.2)
+    if kind == "am":
+        return noise + synth.am_carrier(0, n, FS, 3.0, 0.1, 400.0, 0.5, phase0=0.7)
+    if kind == "dsb":  # suppressed carrier
+        t = np.arange(n) / FS
+        return noise + (0.1 * np.cos(2 * np.pi * 500 * t) * np.exp(1j * (2 * np.pi * 2.0 * t + 0.4))).astype(np.complex64)
+    if kind == "iq":
+        return noise + synth.fm_carrier(0, n, FS, 1500.0, 0.05, 300.0, 800.0)
+    raise ValueError(kind)
+
+
+CASES = {
+    # modes.txt presets restated as channel parameters
+    "usb_agc": dict(sig="usb", demod="linear", low=100.0, high=3000.0, agc=1, hangtime=1.1 * 48000, recovery_rate=RECOVERY,
+                    agc_gain=AGC0, channels=1),
+    "cam_pll": dict(sig="am", demod="linear", low=-5000.0, high=5000.0, pll=1, agc=1, hangtime=1.1 * 48000,
+                    recovery_rate=RECOVERY, agc_gain=AGC0, channels=1),
+    "dsb_square": dict(sig="dsb", demod="linear", low=-5000.0, high=5000.0, pll=1, square=1, agc=1, hangtime=0.0,
+                       recovery_rate=RECOVERY, agc_gain=AGC0, channels=1),
+    "iq_stereo_shift": dict(sig="iq", demod="linear", low=-5000.0, high=5000.0, agc=1, hangtime=100.0,
+                            recovery_rate=RECOVERY, agc_gain=AGC0, channels=2, shift=-700.0 / 48000),
+    "isb": dict(sig="usb", demod="linear", low=-5000.0, high=5000.0, agc=0, agc_gain=2.0, channels=2,
+                out_type=orc.CROSS_CONJ),
+    "am_env": dict(sig="am", demod="linear", low=-5000.0, high=5000.0, env=1, agc=1, hangtime=1.1 * 48000,
+                   recovery_rate=RECOVERY, agc_gain=AGC0, channels=1),
+    "am_c": dict(sig="am", demod="am", low=-5000.0, high=5000.0, hangtime=0.0, recovery_rate=6.0, agc_gain=float("nan")),
+}
+
+
+def test_linear_and_am_bank(hip):
+    T, calls = 4, 4
+    n = T * calls * L
+    names = list(CASES)
+    sigs = {k: _signal(k, n).astype(np.complex64) for k in ("usb", "am", "dsb", "iq")}
+    sig_order = ["usb", "am", "dsb", "iq"]
+    P = len(sig_order)
+    bank = hip.Bank(L, M, D, P, len(names), T, FS)
+    pipe = pipeline.Pipeline(L, M, D, FS, n_inputs=P)
+    demod_id = {"linear": hip.KH_DEMOD_LINEAR, "am": hip.KH_DEMOD_AM}
+    for c, name in enumerate(names):
+        kw = dict(CASES[name])
+        sig = kw.pop("sig")
+        dem = kw.pop("demod")
+        kw.setdefault("headroom", HEADROOM)
+        kw["input"] = sig_order.index(sig)
+        bank.set_channel(c, demod=demod_id[dem], **kw)
+        pipe.add_channel(demod=dem, **kw)
+    for call in range(calls):
+        for i, sname in enumerate(sig_order):
+            bank.write_input(i, sigs[sname][call * T * L:(call + 1) * T * L])
+        bank.execute(T)
+        g_pcm = [bank.pcm(c, T) for c in range(len(names))]
+        g_aud = [bank.audio(c, T) for c in range(len(names))]
+        g_st = [bank.status(c, T) for c in range(len(names))]
+        for b in range(T):
+            lo = (call * T + b) * L
+            outs, _ = pipe.run_block([sigs[s][lo:lo + L] for s in sig_order])
+            for c, name in enumerate(names):
+                _y, audio, sig = outs[c]
+                nch = CASES[name].get("channels", 1) if CASES[name]["demod"] == "linear" and not CASES[name].get("env") else 1
+                sl = slice(b * OLEN * nch, (b + 1) * OLEN * nch)
+                ga = g_aud[c][sl]
+                gp = g_pcm[c][sl]
+                if call == 0 and b == 0:
+                    # start-up: the filter output rises from the rounding floor (1e-8) while agc.gain still
+                    # holds main.c:139's +80 dB, so the first M_dec/2 samples are amplified FFT round-off in
+                    # the reference too.  Compare from the point where the signal has arrived.
+                    skip = 600 * nch
+                    ga, gp, audio = ga[skip:], gp[skip:], audio[skip:]
+                scale = max(float(np.abs(audio).max()), 1e-6)
+                blk = call * T + b
+                # PLL modes: the loop starts on amplified round-off (see above), so its first phase estimates are
+                # noise in the reference too; two correct implementations part by ~1e-3 and the contractive loop
+                # (5 Hz natural frequency) pulls them together again.  Loose bar while it settles, the strict
+                # bars from PLL_SETTLE blocks (160 ms) on.
+                settling = bool(CASES[name].get("pll")) and blk < PLL_SETTLE
+                tol = 1e-2 if settling else 2e-4
+                err = float(np.abs(ga - audio).max()) / scale
+                if os.environ.get("KH_TEST_VERBOSE"):
+                    print(f"{name} call {call} block {b}: audio err {err:.2e}")
+                assert err <= tol, f"{name} block {b} call {call}: audio err {err:.2e} > {tol}"
+                if settling:
+                    continue
+                d = np.abs(gp.astype(np.int32) - orc.scaleclip(audio).astype(np.int32))
+                assert d.max() <= 1, f"{name} block {b} call {call}: pcm max diff {d.max()}"
+                st = g_st[c][b]
+                keys = ["bb_power", "agc_gain"] if CASES[name]["demod"] == "am" else ["bb_power", "agc_gain", "output_level"]
+                for key in keys:
+                    ref = sig[key]
+                    assert abs(st[key] - ref) <= 1e-4 * abs(ref) + 1e-12, (name, key, b, call, st[key], ref)
+                if CASES[name].get("pll"):
+                    assert st["pll_lock"] == sig["pll_lock"]
+                    assert st["lock_timer"] == sig["lock_timer"]
+                    if np.isnan(sig["snr"]):
+                        assert np.isnan(st["snr"])
+                    else:
+                        # linear.c:104: sum(I^2)/sum(Q^2) - 1 with Q the loop's residual phase error times the
+                        # amplitude; the residual is still converging from the start-up split, so the quotient
+                        # is held to 1e-2 (documented exemption from the 1e-4 bar of the other scalars)
+                        assert abs(st["snr"] - sig["snr"]) <= 1e-2 * abs(sig["snr"]) + 1e-6, (name, b, st["snr"], sig["snr"])
+                    assert abs(st["foffset"] - sig["foffset"]) <= 1e-3 * abs(sig["foffset"]) + 1e-3, (name, b, st["foffset"], sig["foffset"])
+                    dphi = abs(st["cphase"] - sig["cphase"])
+                    assert min(dphi, 2 * np.pi - dphi) < 1e-4, (name, b, st["cphase"], sig["cphase"])
+    bank.close()
