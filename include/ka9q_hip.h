@@ -183,6 +183,10 @@ int kh_bank_set_channel(kh_bank *, unsigned int ch, const struct kh_channel_conf
 /* set_second_LO / set_doppler semantics (radio.c:233-240,342-352): f in cycles/sample, rate in
  * cycles/sample^2, phase kept (osc.c:24-27).  The caller applies radio.c:238's negation. */
 int kh_bank_set_lo(kh_bank *, unsigned int input, double lo2_freq, double doppler_freq, double doppler_rate);
+/* the two halves of kh_bank_set_lo on their own: set_second_LO touches only the LO2 oscillator (radio.c:350),
+ * set_doppler only the Doppler one and restarts its sweep from doppler_freq (radio.c:238, osc.c:28-35) */
+int kh_bank_set_second_lo(kh_bank *, unsigned int input, double lo2_freq);
+int kh_bank_set_doppler(kh_bank *, unsigned int input, double doppler_freq, double doppler_rate);
 /* proc_samples' per-packet work (radio.c:132-178) as a bulk upload: append `count` samples of wire
  * format cfg.payload to input's raw ring.  `payload` may be a host or a device pointer. */
 int kh_bank_write_input(kh_bank *, unsigned int input, const void *payload, size_t count);

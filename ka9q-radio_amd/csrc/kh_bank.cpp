@@ -327,6 +327,16 @@ int kh_bank_set_lo(kh_bank *b, unsigned int input, double lo2_freq, double doppl
   b->doppler[input].set(doppler_freq, doppler_rate);   // set_doppler, radio.c:238
   return 0;
 }
+int kh_bank_set_second_lo(kh_bank *b, unsigned int input, double lo2_freq) {
+  if (!b || input >= (unsigned)b->P) return -1;
+  b->lo2[input].set(lo2_freq, 0.0); // radio.c:350
+  return 0;
+}
+int kh_bank_set_doppler(kh_bank *b, unsigned int input, double doppler_freq, double doppler_rate) {
+  if (!b || input >= (unsigned)b->P) return -1;
+  b->doppler[input].set(doppler_freq, doppler_rate); // radio.c:238
+  return 0;
+}
 int kh_bank_set_gain(kh_bank *b, unsigned int input, float gain_factor) {
   if (!b || input >= (unsigned)b->P) return -1;
   b->gain[input] = gain_factor;

@@ -23,7 +23,7 @@ EXPORTS = [
     "create_filter_input", "create_filter_output", "execute_filter_input", "execute_filter_output",
     "delete_filter_input", "delete_filter_output", "make_kaiser", "window_filter", "window_rfilter",
     "set_filter", "noise_gain", "hb15_block", "hb3_block", "kh_decimate_rails",
-    "kh_bank_create", "kh_bank_destroy", "kh_bank_set_channel", "kh_bank_set_lo", "kh_bank_write_input",
+    "kh_bank_create", "kh_bank_destroy", "kh_bank_set_channel", "kh_bank_set_lo", "kh_bank_set_second_lo", "kh_bank_set_doppler", "kh_bank_write_input",
     "kh_bank_write_zeros", "kh_bank_set_gain", "kh_bank_raw_device_ptr", "kh_bank_commit_input",
     "kh_bank_execute", "kh_bank_sync", "kh_bank_read_baseband", "kh_bank_read_pcm", "kh_bank_read_audio",
     "kh_bank_read_status", "kh_bank_read_input_status", "kh_bank_read_spectrum", "kh_bank_read_response",
@@ -129,6 +129,8 @@ def lib():
     L.kh_bank_destroy.argtypes = [C.c_void_p]
     L.kh_bank_set_channel.argtypes = [C.c_void_p, C.c_uint, C.POINTER(ChannelConfig)]
     L.kh_bank_set_lo.argtypes = [C.c_void_p, C.c_uint, C.c_double, C.c_double, C.c_double]
+    L.kh_bank_set_second_lo.argtypes = [C.c_void_p, C.c_uint, C.c_double]
+    L.kh_bank_set_doppler.argtypes = [C.c_void_p, C.c_uint, C.c_double, C.c_double]
     L.kh_bank_set_gain.argtypes = [C.c_void_p, C.c_uint, C.c_float]
     L.kh_bank_write_input.argtypes = [C.c_void_p, C.c_uint, C.c_void_p, C.c_size_t]
     L.kh_bank_write_zeros.argtypes = [C.c_void_p, C.c_uint, C.c_size_t]
@@ -275,6 +277,12 @@ class Bank:
 
     def set_lo(self, inp, lo2, doppler=0.0, doppler_rate=0.0):
         _check(self.lib.kh_bank_set_lo(self.h, inp, lo2, doppler, doppler_rate), "kh_bank_set_lo")
+
+    def set_second_lo(self, inp, lo2):
+        _check(self.lib.kh_bank_set_second_lo(self.h, inp, lo2), "kh_bank_set_second_lo")
+
+    def set_doppler(self, inp, f, rate=0.0):
+        _check(self.lib.kh_bank_set_doppler(self.h, inp, f, rate), "kh_bank_set_doppler")
 
     def set_gain(self, inp, g):
         _check(self.lib.kh_bank_set_gain(self.h, inp, g), "kh_bank_set_gain")

@@ -1,0 +1,295 @@
+"""GPU parity on the BASELINE.json configurations 3, 4 and 5 (SURVEY.md 8 shape table).
+
+The oracle is run on a handful of channels per configuration (it needs ~0.1 s per 2^20-point block); the full
+channel counts are covered through size-independent properties: channels are independent (a channel's output does
+not depend on which other channels exist), identical channels give identical bits, and spot-checked channels of
+the full-size bank match the oracle."""
+import numpy as np
+import pytest
+
+import orc
+import pipeline
+import synth
+from conftest import rel_rms
+
+pytestmark = pytest.mark.gpu
+
+HEADROOM = 10 ** (-15 / 20)
+AGC0 = 10 ** (80 / 20)
+
+
+def _recovery(out_rate):
+    return 10 ** ((6.0 / out_rate) / 20)  # +6 dB/s (radio.c:398)
+
+
+def _check_channel(name, kind, g_bb, g_pcm, g_st, outs_by_block, olen, nch=1, settle=0, skip0=0):
+    for b, (y, audio, sig) in enumerate(outs_by_block):
+        sl = slice(b * olen, (b + 1) * olen)
+        if kind != "linear_pll":  # linear.c:91 rewrites the baseband when the PLL runs
+            if not (kind.startswith("linear") and nch == 2):  # linear.c:145 rewrites it for stereo output
+                assert rel_rms(g_bb[sl], y) < 1e-5, (name, b)
+        if b < settle:
+            continue
+        slp = slice(b * olen * nch, (b + 1) * olen * nch)
+        gp, want = g_pcm[slp], orc.scaleclip(audio)
+        if b == 0 and skip0:
+            gp, want = gp[skip0 * nch:], want[skip0 * nch:]
+        d = np.abs(gp.astype(np.int32) - want.astype(np.int32))
+        assert d.max() <= 1, (name, b, int(d.max()))
+        ref = sig["bb_power"]
+        assert abs(g_st[b]["bb_power"] - ref) <= 1e-4 * abs(ref) + 1e-15, (name, b)
+
+
+def _n0_float64(spec, N, low, high, samprate):
+    """compute_n0 (radio.c:422-465) with the two means accumulated in float64 instead of serially in float32."""
+    low_n = int(np.float32(N * np.float32(low)) / np.float32(samprate))
+    high_n = int(np.float32(N * np.float32(high)) / np.float32(samprate))
+    bincount = N - (high_n - low_n)
+    idx = (high_n + 1 + np.arange(bincount)) % N
+    p = (spec[idx].real.astype(np.float32) ** 2 + spec[idx].imag.astype(np.float32) ** 2).astype(np.float64)
+    avg = p.mean()
+    sel = p < 2 * avg
+    return p[sel].mean() / (float(N) * samprate)
+
+
+def test_config3_20MSps_mixed_modes(hip):
+    """20 MS/s, N = 2^19, D = 512 -> 39.0625 kS/s; k mod 4 = 0,1 NBFM, 2 envelope AM with AGC, 3 USB with hang AGC."""
+    fs, L, M, D = 20_000_000, 262144, 262145, 512
+    N = L + M - 1
+    olen = L // D
+    out_rate = fs / D
+    T, calls = 2, 2
+    n = T * calls * L
+    ks = [-6, -5, -2, -1, 0, 1, 2, 3]
+    x = synth.noise(n, 0.01, 31)
+    cfgs = []
+    for k in ks:
+        rot = synth.rotate_for(k, 12500.0, N, fs)
+        fc = rot * fs / N
+        m = k % 4
+        if m in (0, 1):
+            x = x + synth.fm_carrier(0, n, fs, fc, 0.05, 300.0 + 50 * (k % 8), 2500.0, phase0=0.1 * k)
+            cfgs.append(("fm", dict(demod="fm", rotate=rot, low=-5500.0, high=5500.0, headroom=HEADROOM)))
+        elif m == 2:
+            x = x + synth.am_carrier(0, n, fs, fc, 0.05, 400.0, 0.5, phase0=0.3)
+            cfgs.append(("linear_env", dict(demod="linear", rotate=rot, low=-5000.0, high=5000.0, env=1, agc=1,
+                                            hangtime=1.1 * out_rate, recovery_rate=_recovery(out_rate), agc_gain=AGC0,
+                                            headroom=HEADROOM)))
+        else:
+            x = x + synth.usb_two_tone(0, n, fs, fc, 0.05)
+            cfgs.append(("linear_usb", dict(demod="linear", rotate=rot, low=100.0, high=3000.0, agc=1,
+                                            hangtime=1.1 * out_rate, recovery_rate=_recovery(out_rate), agc_gain=AGC0,
+                                            headroom=HEADROOM)))
+    x = x.astype(np.complex64)
+    C = len(cfgs)
+    bank = hip.Bank(L, M, D, 1, C, T, fs)
+    pipe = pipeline.Pipeline(L, M, D, fs)
+    did = {"fm": hip.KH_DEMOD_FM, "linear": hip.KH_DEMOD_LINEAR}
+    for c, (_kind, kw) in enumerate(cfgs):
+        kwb = dict(kw)
+        kwb["demod"] = did[kw["demod"]]
+        bank.set_channel(c, **kwb)
+        pipe.add_channel(**kw)
+    for call in range(calls):
+        seg = x[call * T * L:(call + 1) * T * L]
+        bank.write_input(0, seg)
+        bank.execute(T)
+        per_block = [pipe.run_block([seg[b * L:(b + 1) * L]])[0] for b in range(T)]
+        for c, (kind, _kw) in enumerate(cfgs):
+            _check_channel(f"c3 ch{c} {kind} call{call}", kind, bank.baseband(c, T), bank.pcm(c, T), bank.status(c, T),
+                           [pb[c] for pb in per_block], olen, skip0=300 if call == 0 else 0)
+    bank.close()
+
+
+def test_config4_64MSps_2pow20(hip):
+    """64 MS/s, N = 2^20, D = 2048 -> 31.25 kS/s, N_dec = 512, olen = 256; NBFM channels across the whole band
+    including both band edges (rotate near +-N/2 exercises the modular wrap of filter.c:278-289)."""
+    fs, L, M, D = 64_000_000, 524288, 524289, 2048
+    N = L + M - 1
+    olen = L // D
+    T, calls = 2, 2
+    n = T * calls * L
+    ks = [-2559, -2048, -1, 0, 1, 777, 2047, 2559]
+    sigs = [(k, 0.03 + 0.005 * i, 300.0 + 70 * i, 2500.0) for i, k in enumerate(ks)]
+    x = synth.wideband_fm(0, n, fs, N, sigs)
+    C = len(ks)
+    bank = hip.Bank(L, M, D, 1, C, T, fs, compute_n0=1, n0_low=-5500.0, n0_high=5500.0)
+    pipe = pipeline.Pipeline(L, M, D, fs, compute_n0=True, n0_low=-5500.0, n0_high=5500.0)
+    for c, k in enumerate(ks):
+        kw = dict(rotate=synth.rotate_for(k, 12500.0, N, fs), low=-5500.0, high=5500.0, headroom=HEADROOM)
+        bank.set_channel(c, demod=hip.KH_DEMOD_FM, **kw)
+        pipe.add_channel(demod="fm", **kw)
+    n0_prev = None
+    for call in range(calls):
+        seg = x[call * T * L:(call + 1) * T * L]
+        bank.write_input(0, seg)
+        bank.execute(T)
+        ist = bank.input_status(0, T)
+        per_block = []
+        for b in range(T):
+            outs, istat = pipe.run_block([seg[b * L:(b + 1) * L]])
+            per_block.append(outs)
+            # radio.c:450-462 adds ~10^6 float32 terms one after the other: at this size the serial sum itself is
+            # only good to ~sqrt(n)*eps ~ 1e-4 (and the reference's -funsafe-math build re-associates it anyway), so
+            # the oracle is held to 1e-3 and the 1e-4 bar is applied against the same definition summed in float64
+            assert abs(ist[b]["n0"] - istat[0][1]) <= 1e-3 * abs(istat[0][1]), (call, b)
+            n0_64 = _n0_float64(pipe.spectrum(0), N, -5500.0, 5500.0, fs)
+            n0_prev = n0_64 if n0_prev is None else n0_prev + .005 * (n0_64 - n0_prev)  # radio.c:199-202
+            assert abs(ist[b]["n0"] - n0_prev) <= 1e-4 * n0_prev, (call, b, float(ist[b]["n0"]), n0_prev)
+            if b == 0:
+                assert rel_rms(bank.spectrum(0, 0), pipe.spectrum(0)) < 1e-5
+        for c in range(C):
+            _check_channel(f"c4 ch{c} call{call}", "fm", bank.baseband(c, T), bank.pcm(c, T), bank.status(c, T),
+                           [pb[c] for pb in per_block], olen)
+    bank.close()
+
+
+def test_config4_full_size_properties(hip):
+    """512 channels at N = 2^20 (one GPU's share of config 4), 4 blocks: (i) channel results do not depend on the
+    other channels: a spot-checked channel equals the same channel computed alone; (ii) duplicate channels are
+    bit-identical; (iii) three spot-checked channels match the oracle."""
+    fs, L, M, D = 64_000_000, 524288, 524289, 2048
+    N = L + M - 1
+    olen = L // D
+    T, C = 4, 512
+    ks = list(range(-256, 256))
+    ks[500] = ks[10]  # a duplicate
+    strong = {ks[10]: 0.05, ks[100]: 0.03, ks[333]: 0.04}
+    sigs = [(k, a, 400.0 + (k % 7) * 50, 2500.0) for k, a in strong.items()]
+    x = synth.wideband_fm(0, T * L, fs, N, sigs)
+    bank = hip.Bank(L, M, D, 1, C, T, fs)
+    for c, k in enumerate(ks):
+        bank.set_channel(c, demod=hip.KH_DEMOD_FM, rotate=synth.rotate_for(k, 12500.0, N, fs), low=-5500.0, high=5500.0)
+    bank.write_input(0, x)
+    bank.execute(T)
+    full = {c: (bank.baseband(c, T), bank.pcm(c, T)) for c in (10, 100, 333, 500, 0, 511)}
+    bank.close()
+    assert np.array_equal(full[10][0], full[500][0]) and np.array_equal(full[10][1], full[500][1])
+    assert np.abs(full[10][1]).max() > 500 and np.abs(full[0][1]).max() == 0  # open / squelched
+    solo = hip.Bank(L, M, D, 1, 1, T, fs)
+    solo.set_channel(0, demod=hip.KH_DEMOD_FM, rotate=synth.rotate_for(ks[333], 12500.0, N, fs), low=-5500.0, high=5500.0)
+    solo.write_input(0, x)
+    solo.execute(T)
+    assert np.array_equal(solo.baseband(0, T), full[333][0]) and np.array_equal(solo.pcm(0, T), full[333][1])
+    solo.close()
+    pipe = pipeline.Pipeline(L, M, D, fs)
+    for c in (10, 100, 333):
+        pipe.add_channel(demod="fm", rotate=synth.rotate_for(ks[c], 12500.0, N, fs), low=-5500.0, high=5500.0)
+    for b in range(T):
+        outs, _ = pipe.run_block([x[b * L:(b + 1) * L]])
+        for j, c in enumerate((10, 100, 333)):
+            y, audio, _sig = outs[j]
+            sl = slice(b * olen, (b + 1) * olen)
+            assert rel_rms(full[c][0][sl], y) < 1e-5, (c, b)
+            assert np.abs(full[c][1][sl].astype(np.int32) - orc.scaleclip(audio).astype(np.int32)).max() <= 1, (c, b)
+
+
+def _c5_case(i, fs):
+    rng = np.random.default_rng(1000 + i)
+    f0 = float(rng.uniform(-10e3, 10e3))
+    fdot = float(rng.uniform(-200.0, 200.0))
+    return f0, fdot, bool(i % 2)  # odd pipelines: suppressed carrier, squaring loop
+
+
+def _c5_signal(i, n, fs):
+    f0, fdot, square = _c5_case(i, fs)
+    nz = synth.noise(n, 0.001, 200 + i)
+    if square:
+        t = np.arange(n, dtype=np.float64) / fs
+        ph = 2 * np.pi * ((48_000.0 + f0) * t + 0.5 * fdot * t * t) + 0.4
+        return (nz + (0.1 * np.cos(2 * np.pi * 500 * t) * np.exp(1j * ph)).astype(np.complex64)).astype(np.complex64)
+    return (nz + synth.swept_carrier(0, n, fs, 48_000.0 + f0, fdot, 0.1)).astype(np.complex64)
+
+
+def _c5_channel_kw(i):
+    _f0, _fdot, square = _c5_case(i, 192000)
+    return dict(demod="linear", input=i, low=-5000.0, high=5000.0, pll=1, square=int(square), agc=1,
+                hangtime=1.1 * 48000, recovery_rate=_recovery(48000), agc_gain=AGC0, headroom=HEADROOM)
+
+
+def test_config5_pipelines_doppler_pll_agc(hip):
+    """Independent 192 kS/s pipelines in the reference's order: Doppler NCO with sweep (set_doppler, radio.c:233-240,
+    sign convention of radio.c:238) -> LO2 NCO -> filter -> demod_linear with PLL + AGC; state carried over 5 launches
+    of 5 blocks (0.5 s: NCO renormalisation every 16384 samples, PLL pull-in, lock counter running)."""
+    fs, L, M, D = 192_000, 3840, 4353, 4
+    olen = L // D
+    P, T, calls = 6, 5, 5
+    n = T * calls * L
+    sig = [_c5_signal(i, n, fs) for i in range(P)]
+    bank = hip.Bank(L, M, D, P, P, T, fs)
+    pipe = pipeline.Pipeline(L, M, D, fs, n_inputs=P)
+    for i in range(P):
+        f0, fdot, _sq = _c5_case(i, fs)
+        kw = _c5_channel_kw(i)
+        kwb = dict(kw)
+        kwb["demod"] = hip.KH_DEMOD_LINEAR
+        bank.set_channel(i, **kwb)
+        pipe.add_channel(**kw)
+        # open-loop correction: the negated Doppler (radio.c:238) and the -48 kHz second LO
+        args = (-48_000.0 / fs, -f0 / fs, -(fdot / fs) / fs)
+        bank.set_lo(i, *args)
+        pipe.set_lo(i, *args)
+    SETTLE = 10  # blocks: PLL start-up on amplified round-off, see tests/test_gpu_bank_linear.py
+    for call in range(calls):
+        for i in range(P):
+            bank.write_input(i, sig[i][call * T * L:(call + 1) * T * L])
+        bank.execute(T)
+        g_aud = [bank.audio(i, T) for i in range(P)]
+        g_pcm = [bank.pcm(i, T) for i in range(P)]
+        g_st = [bank.status(i, T) for i in range(P)]
+        for b in range(T):
+            lo = (call * T + b) * L
+            outs, _ = pipe.run_block([sig[i][lo:lo + L] for i in range(P)])
+            blk = call * T + b
+            for i in range(P):
+                _y, audio, s = outs[i]
+                sl = slice(b * olen, (b + 1) * olen)
+                if blk == 0:
+                    continue
+                scale = max(float(np.abs(audio).max()), 1e-6)
+                err = float(np.abs(g_aud[i][sl] - audio).max()) / scale
+                assert err <= (2e-2 if blk < SETTLE else 3e-4), (i, blk, err)
+                if blk < SETTLE:
+                    continue
+                assert np.abs(g_pcm[i][sl].astype(np.int32) - orc.scaleclip(audio).astype(np.int32)).max() <= 1, (i, blk)
+                st = g_st[i][b]
+                assert st["pll_lock"] == s["pll_lock"] and st["lock_timer"] == s["lock_timer"]
+                assert abs(st["agc_gain"] - s["agc_gain"]) <= 1e-4 * abs(s["agc_gain"])
+                assert abs(st["foffset"] - s["foffset"]) <= 1e-3 * abs(s["foffset"]) + 2e-3, (i, blk, st["foffset"], s["foffset"])
+    # the open-loop Doppler correction left a residual the PLL can hold: |foffset| is a few Hz, not kHz
+    assert all(abs(g_st[i][T - 1]["foffset"]) < 50.0 for i in range(P))
+    bank.close()
+
+
+def test_config5_full_256_pipelines_independent(hip):
+    """256 pipelines in one bank: pipelines 0..5 of the full bank produce the same bits as the 6-pipeline bank of the
+    previous test's first launch (per-lane recurrences must not leak between lanes or wavefronts)."""
+    fs, L, M, D = 192_000, 3840, 4353, 4
+    P, T = 256, 5
+    n = T * L
+    small = hip.Bank(L, M, D, 6, 6, T, fs)
+    big = hip.Bank(L, M, D, P, P, T, fs)
+    sigs = {}
+    for i in range(P):
+        j = i % 6 if i >= 6 else i  # inputs repeat with period 6 above pipeline 5: identical channels, identical bits
+        if j not in sigs:
+            sigs[j] = _c5_signal(j, n, fs)
+        f0, fdot, _sq = _c5_case(j, fs)
+        kw = _c5_channel_kw(j)
+        kw["demod"] = hip.KH_DEMOD_LINEAR
+        kw["input"] = i
+        big.set_channel(i, **kw)
+        big.set_lo(i, -48_000.0 / fs, -f0 / fs, -(fdot / fs) / fs)
+        big.write_input(i, sigs[j])
+        if i < 6:
+            small.set_channel(i, **kw)
+            small.set_lo(i, -48_000.0 / fs, -f0 / fs, -(fdot / fs) / fs)
+            small.write_input(i, sigs[j])
+    small.execute(T)
+    big.execute(T)
+    for i in range(6):
+        assert np.array_equal(small.pcm(i, T), big.pcm(i, T)), i
+        assert np.array_equal(big.pcm(i, T), big.pcm(i + 6 * 41, T)), i  # pipeline 246+i repeats pipeline i
+        assert small.status(i, T).tobytes() == big.status(i, T).tobytes()
+    small.close()
+    big.close()
