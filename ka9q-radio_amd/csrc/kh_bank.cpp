@@ -439,18 +439,23 @@ int kh_bank_execute(kh_bank *b, unsigned int nblocks) {
   };
   float2 *time = b->d_time[b->cur];
   mark(); // 0
+  // the last M-1 samples of the launch are the next launch's overlap-save history (filter.c:230): ingest stores
+  // them at the head of the other buffer as it goes, unless the history reaches back beyond this launch
+  bool const fused_carry = (size_t)(M - 1) <= need;
   if (launch_ingest(st, b->d_raw, b->raw_stride, b->cfg.payload, time + (M - 1), b->time_stride, b->d_idesc, b->d_energy,
-                    L, nblocks, P))
+                    L, nblocks, P, fused_carry ? b->d_time[b->cur ^ 1] : nullptr, need - (fused_carry ? (M - 1) : 0)))
     return -1;
   mark(); // 1
   // launch_forward_fft records the mid event (ev[2]) between the two passes itself
+  N0Plan const plan = n0_plan(N, b->cfg.samprate, b->cfg.n0_low, b->cfg.n0_high);
+  bool const n0_on = b->cfg.compute_n0 && plan.valid;
   if (launch_forward_fft(st, time, b->time_stride, 0, b->d_spec, b->d_tmp, b->spec_stride, N, L, nblocks, P,
-                         prof ? b->ev[2] : nullptr))
+                         prof ? b->ev[2] : nullptr, N0Fuse{n0_on ? b->d_n0acc : nullptr, plan.start, plan.bincount}))
     return -1;
   e = 3;
   mark(); // 3
-  if (launch_n0(st, b->cfg.compute_n0 ? b->d_spec : nullptr, b->spec_stride, N, b->cfg.samprate, b->cfg.n0_low,
-                b->cfg.n0_high, b->d_energy, L, b->d_n0state, b->d_n0acc, b->d_istatus, nblocks, P))
+  if (launch_n0(st, b->cfg.compute_n0 ? b->d_spec : nullptr, b->spec_stride, N, b->cfg.samprate, plan, b->d_energy, L,
+                b->d_n0state, b->d_n0acc, b->d_istatus, nblocks, P))
     return -1;
   mark(); // 4
   if (launch_filter_output(st, b->d_spec, b->spec_stride, N, 0, b->d_chans, b->d_resp, b->ND, b->olen, b->d_bb,
@@ -465,8 +470,8 @@ int kh_bank_execute(kh_bank *b, unsigned int nblocks) {
   if (b->n_fm) b->fm_parity ^= 1;
   mark(); // 6
   // overlap-save history for the next call (filter.c:230), into the other buffer
-  if (launch_carry(st, time + need, b->d_time[b->cur ^ 1], b->time_stride * sizeof(float2), (size_t)(M - 1) * sizeof(float2),
-                   P))
+  if (!fused_carry && launch_carry(st, time + need, b->d_time[b->cur ^ 1], b->time_stride * sizeof(float2),
+                                   (size_t)(M - 1) * sizeof(float2), P))
     return -1;
   mark(); // 7
   b->cur ^= 1;

@@ -69,12 +69,15 @@ __device__ __forceinline__ float2 load_raw(const unsigned char *raw, size_t n, i
   }
 }
 
-// grid (chunks per block, nblocks, ninputs), 256 threads, 4 samples per thread
+// grid (chunks per block, nblocks, ninputs), 256 threads, INGEST_CHUNK/256 samples per thread
 // algorithmic bytes per sample: wire bytes read + 8 written
+// hist_dst: the other time buffer.  The last hist_len samples of the launch (n >= hist_from) are stored there as
+// well, at its head: they are the overlap-save history of the next launch (filter.c:230's memmove).
+constexpr int INGEST_CHUNK = 4096;
 __global__ __launch_bounds__(256) void kh_ingest(const unsigned char *__restrict__ raw, size_t raw_stride_bytes,
                                                  int payload, float2 *__restrict__ time, size_t time_stride,
                                                  const IngestDesc *__restrict__ descs, float *__restrict__ energy_part,
-                                                 int L, int nblocks) {
+                                                 int L, int nblocks, float2 *__restrict__ hist_dst, size_t hist_from) {
   __shared__ float part[4];
   int const b = blockIdx.y, i = blockIdx.z;
   const IngestDesc *dp = descs + i;
@@ -82,10 +85,11 @@ __global__ __launch_bounds__(256) void kh_ingest(const unsigned char *__restrict
   int const dop_active = dp->doppler.active, lo_active = dp->lo2.active;
   const unsigned char *src = raw + (size_t)i * raw_stride_bytes;
   float2 *dst = time + (size_t)i * time_stride;
+  float2 *hdst = hist_dst ? hist_dst + (size_t)i * time_stride : nullptr;
   float energy = 0.f;
-#pragma unroll
-  for (int u = 0; u < 4; u++) {
-    int const k = blockIdx.x * 1024 + u * 256 + threadIdx.x;
+#pragma unroll 4
+  for (int u = 0; u < INGEST_CHUNK / 256; u++) {
+    int const k = blockIdx.x * INGEST_CHUNK + u * 256 + threadIdx.x;
     if (k < L) {
       size_t const n = (size_t)b * L + k;
       float2 x = load_raw(src, n, payload, gain_factor);
@@ -105,6 +109,7 @@ __global__ __launch_bounds__(256) void kh_ingest(const unsigned char *__restrict
       }
       energy += x.x * x.x + x.y * x.y; // radio.c:188
       dst[n] = x;
+      if (hdst != nullptr && n >= hist_from) hdst[n - hist_from] = x;
     }
   }
   energy = wave_sum(energy);
@@ -114,47 +119,51 @@ __global__ __launch_bounds__(256) void kh_ingest(const unsigned char *__restrict
     energy_part[((size_t)i * nblocks + b) * gridDim.x + blockIdx.x] = part[0] + part[1] + part[2] + part[3];
 }
 
-int ingest_chunks(int L) { return (L + 1023) / 1024; }
+int ingest_chunks(int L) { return (L + INGEST_CHUNK - 1) / INGEST_CHUNK; }
 
 int launch_ingest(hipStream_t st, const void *raw, size_t raw_stride_bytes, int payload, float2 *time,
-                  size_t time_stride, const IngestDesc *desc, float *energy_part, int L, int nblocks, int ninputs) {
+                  size_t time_stride, const IngestDesc *desc, float *energy_part, int L, int nblocks, int ninputs,
+                  float2 *hist_dst, size_t hist_from) {
   if (nblocks <= 0 || ninputs <= 0) return 0;
   hipLaunchKernelGGL(kh_ingest, dim3(ingest_chunks(L), nblocks, ninputs), dim3(256), 0, st,
                      static_cast<const unsigned char *>(raw), raw_stride_bytes, payload, time, time_stride, desc,
-                     energy_part, L, nblocks);
+                     energy_part, L, nblocks, hist_dst, hist_from);
   return KH_HIP(hipGetLastError()) ? 0 : -1;
 }
 
 // ================================================================ compute_n0: radio.c:422-465
-// pass 0: sum of |X|^2 over the bins outside the passband; pass 1: sum and count of those below twice that
-// mean.  Every workgroup leaves its partial sums in `part` ([input][block][N0_GX] x {sum0, sum1, count1});
-// kh_n0_final adds them up in a fixed order (no atomics: the result is reproducible run to run).
-// algorithmic bytes: 8*bincount per pass
-constexpr int N0_GX = 64; // workgroups per (input, block)
+// Iteration 0 of radio.c:451-462 (sum of |X|^2 over every bin outside the passband) is left by the forward
+// transform's epilogue (kh_fft_rows / kh_fft_fwd_lds) as n0_partials(N) partial sums per (input, block).
+// kh_n0_pass1 is iteration 1: sum and count of the bins below twice that mean, N0_GX partials per (input, block).
+// kh_n0_final adds them up in a fixed order (no atomics: reproducible run to run) and applies the smoothing of
+// radio.c:197-202 block by block.
+// algorithmic bytes: 8*bincount
+constexpr int N0_GX = 64; // workgroups per (input, block) in kh_n0_pass1
 
-template <int PASS>
-__global__ __launch_bounds__(256) void kh_n0_pass(const float2 *__restrict__ spec, size_t spec_in_stride, int N,
-                                                  int start, int bincount, float *__restrict__ part, int nblocks) {
+// part layout: [0, PT*N0_SLOTS) first-pass sums; then PT*N0_GX pairs {sum1, count1}   (PT = ninputs*nblocks)
+__global__ __launch_bounds__(256) void kh_n0_pass1(const float2 *__restrict__ spec, size_t spec_in_stride, int N,
+                                                   int start, int bincount, float *__restrict__ part, int nblocks,
+                                                   int npart0) {
   __shared__ float ps[4], pc[4];
   int const b = blockIdx.y, i = blockIdx.z;
   const float2 *fd = spec + (size_t)i * spec_in_stride + (size_t)b * N;
-  float *a = part + 3 * N0_GX * ((size_t)i * nblocks + b);
-  float thresh = INFINITY;
-  if (PASS == 1) { // radio.c:456,461: twice the mean of pass 0
-    float t = threadIdx.x < N0_GX ? a[3 * threadIdx.x] : 0.f;
-    t = wave_sum(t); // N0_GX == 64: all partials sit in wave 0; the other waves add zeros
-    if ((threadIdx.x & 63) == 0) ps[threadIdx.x >> 6] = t;
-    __syncthreads();
-    thresh = (ps[0] / bincount) * 2;
-    __syncthreads();
-  }
+  size_t const pt = (size_t)i * nblocks + b;
+  const float *p0 = part + pt * N0_SLOTS;
+  float *p1 = part + (size_t)gridDim.z * nblocks * N0_SLOTS + pt * (2 * N0_GX);
+  // radio.c:456,461: twice the mean of iteration 0 (npart0 <= 64 partials, added in a fixed order)
+  float t = threadIdx.x < npart0 ? p0[threadIdx.x] : 0.f;
+  t = wave_sum(t);
+  if ((threadIdx.x & 63) == 0) ps[threadIdx.x >> 6] = t; // all partials sit in wave 0
+  __syncthreads();
+  float const th = (ps[0] / bincount) * 2;
+  __syncthreads();
   float s = 0.f, c = 0.f;
   for (int n = blockIdx.x * 256 + threadIdx.x; n < bincount; n += N0_GX * 256) {
     int in = start + n; // radio.c:440-446
     if (in >= N) in -= N;
     float2 const x = fd[in];
     float const p = x.x * x.x + x.y * x.y;
-    if (p < thresh) {
+    if (p < th) {
       s += p;
       c += 1.f;
     }
@@ -167,39 +176,39 @@ __global__ __launch_bounds__(256) void kh_n0_pass(const float2 *__restrict__ spe
   }
   __syncthreads();
   if (threadIdx.x == 0) {
-    if (PASS == 0)
-      a[3 * blockIdx.x] = ps[0] + ps[1] + ps[2] + ps[3];
-    else {
-      a[3 * blockIdx.x + 1] = ps[0] + ps[1] + ps[2] + ps[3];
-      a[3 * blockIdx.x + 2] = pc[0] + pc[1] + pc[2] + pc[3];
-    }
+    p1[2 * blockIdx.x] = ps[0] + ps[1] + ps[2] + ps[3];
+    p1[2 * blockIdx.x + 1] = pc[0] + pc[1] + pc[2] + pc[3];
   }
 }
 
-// one workgroup per input: each wave adds up the partials of a block (fixed order: reproducible), then lane 0
-// applies radio.c:197-202 block by block from LDS
+// one workgroup per input, one wave per block (16 waves: 16 blocks at a time; every lane issues all of its loads
+// before the first shuffle, so a block costs one memory round trip), then lane 0 applies radio.c:197-202 block by
+// block from LDS
 constexpr int N0_MAXB = 1024; // blocks per launch the smoothing pass can hold
-__global__ __launch_bounds__(256) void kh_n0_final(const float *__restrict__ part, const float *__restrict__ energy_part,
-                                                   int echunks, int L, int N, int samprate, int valid, int have_n0,
-                                                   float *__restrict__ n0_state, kh_input_status *__restrict__ status,
-                                                   int nblocks) {
+constexpr int N0_FT = 1024;
+__global__ __launch_bounds__(N0_FT) void kh_n0_final(const float *__restrict__ part, const float *__restrict__ energy_part,
+                                                     int echunks, int L, int N, int samprate, int valid, int have_n0,
+                                                     float *__restrict__ n0_state, kh_input_status *__restrict__ status,
+                                                     int nblocks) {
   __shared__ float sv[N0_MAXB], se[N0_MAXB];
   int const i = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  for (int b = wave; b < nblocks; b += 4) {
-    const float *e = energy_part + ((size_t)i * nblocks + b) * echunks;
+  const float *part1 = part + (size_t)gridDim.x * nblocks * N0_SLOTS;
+  for (int b = wave; b < nblocks; b += N0_FT / 64) {
+    size_t const pt = (size_t)i * nblocks + b;
+    const float *e = energy_part + pt * echunks;
     float es = 0.f;
     for (int k = lane; k < echunks; k += 64) es += e[k];
-    es = wave_sum(es);
-    float v = NAN;
-    if (have_n0) {
-      v = 0.f; // "Can this happen?" radio.c:433-435
-      if (valid) {
-        const float *a = part + 3 * N0_GX * ((size_t)i * nblocks + b);
-        float s1 = wave_sum(a[3 * lane + 1]); // N0_GX == 64 partials, one per lane
-        float c1 = wave_sum(a[3 * lane + 2]);
-        v = (s1 / c1) / ((float)N * samprate); // radio.c:461,464
-      }
+    float s1 = 0.f, c1 = 0.f;
+    if (have_n0 && valid) {
+      float2 const sc = reinterpret_cast<const float2 *>(part1 + pt * (2 * N0_GX))[lane]; // N0_GX == 64: one per lane
+      s1 = sc.x;
+      c1 = sc.y;
     }
+    es = wave_sum(es);
+    s1 = wave_sum(s1);
+    c1 = wave_sum(c1);
+    float v = NAN;
+    if (have_n0) v = valid ? (s1 / c1) / ((float)N * samprate) : 0.f; // radio.c:433-435 ("Can this happen?"), 461, 464
     if (lane == 0) {
       se[b] = es / L; // radio.c:197
       sv[b] = v;
@@ -219,15 +228,32 @@ __global__ __launch_bounds__(256) void kh_n0_final(const float *__restrict__ par
     n0_state[i] = n0;
   }
   __syncthreads();
-  for (int b = threadIdx.x; b < nblocks; b += 256) {
+  for (int b = threadIdx.x; b < nblocks; b += N0_FT) {
     status[(size_t)i * nblocks + b].if_power = se[b];
     status[(size_t)i * nblocks + b].n0 = sv[b];
   }
 }
 
-int n0_part_floats() { return 3 * N0_GX; }
+int n0_part_floats() { return N0_SLOTS + 2 * N0_GX; }
 
-int launch_n0(hipStream_t st, const float2 *spec, size_t spec_in_stride, int N, int samprate, float low, float high,
+N0Plan n0_plan(int N, int samprate, float low, float high) {
+  N0Plan p{0, 0, 0};
+  int const low_n = (int)((N * low) / samprate); // radio.c:430-431: float arithmetic, truncated
+  int const high_n = (int)((N * high) / samprate);
+  int const bincount = N - (high_n - low_n);
+  p.valid = !(bincount < 0 || bincount > N) && bincount > 0;
+  int start = high_n + 1;
+  if (start >= N)
+    start -= N;
+  else if (start < 0)
+    start += N;
+  p.start = start;
+  p.bincount = bincount;
+  return p;
+}
+
+// second iteration + smoothing + IF power; the forward transform has left the first-iteration partials in `part`
+int launch_n0(hipStream_t st, const float2 *spec, size_t spec_in_stride, int N, int samprate, N0Plan plan,
               const float *energy_part, int L, float *n0_state, float *part, void *input_status, int nblocks,
               int ninputs) {
   if (nblocks <= 0 || ninputs <= 0) return 0;
@@ -237,25 +263,11 @@ int launch_n0(hipStream_t st, const float2 *spec, size_t spec_in_stride, int N, 
   }
   kh_input_status *status = static_cast<kh_input_status *>(input_status);
   int const have_n0 = spec != nullptr;
-  int valid = 0;
-  if (have_n0) {
-    int const low_n = (int)((N * low) / samprate); // radio.c:430-431: float arithmetic, truncated
-    int const high_n = (int)((N * high) / samprate);
-    int const bincount = N - (high_n - low_n);
-    valid = !(bincount < 0 || bincount > N) && bincount > 0;
-    int start = high_n + 1;
-    if (start >= N)
-      start -= N;
-    else if (start < 0)
-      start += N;
-    if (valid) {
-      hipLaunchKernelGGL(kh_n0_pass<0>, dim3(N0_GX, nblocks, ninputs), dim3(256), 0, st, spec, spec_in_stride, N, start,
-                         bincount, part, nblocks);
-      hipLaunchKernelGGL(kh_n0_pass<1>, dim3(N0_GX, nblocks, ninputs), dim3(256), 0, st, spec, spec_in_stride, N, start,
-                         bincount, part, nblocks);
-    }
-  }
-  hipLaunchKernelGGL(kh_n0_final, dim3(ninputs), dim3(256), 0, st, part, energy_part, ingest_chunks(L), L, N, samprate,
+  int const valid = have_n0 && plan.valid;
+  if (valid)
+    hipLaunchKernelGGL(kh_n0_pass1, dim3(N0_GX, nblocks, ninputs), dim3(256), 0, st, spec, spec_in_stride, N, plan.start,
+                       plan.bincount, part, nblocks, n0_partials(N));
+  hipLaunchKernelGGL(kh_n0_final, dim3(ninputs), dim3(N0_FT), 0, st, part, energy_part, ingest_chunks(L), L, N, samprate,
                      valid, have_n0, n0_state, status, nblocks);
   return KH_HIP(hipGetLastError()) ? 0 : -1;
 }

@@ -8,6 +8,7 @@
 // Roofline: everything here streams; HBM bound.  No MFMA: nothing is a dense contraction.
 #include "kh_internal.h"
 #include "kh_fft.cuh"
+#include "kh_regfft.cuh"
 #include "kh_fm.cuh"
 
 namespace kh {
@@ -16,11 +17,20 @@ enum { FT_NONE = 0, FT_COMPLEX = 1, FT_CROSS_CONJ = 2, FT_REAL = 3 }; // filter.
 
 // ================================================================ forward FFT, N <= 8192: one workgroup per block
 // algorithmic bytes per launch: nblocks*ninputs*(8N read + 8N write)
+// n0: when n0.part is set, the epilogue also leaves compute_n0's first-pass sum for this block (radio.c:450-461,
+// iteration 0: every bin outside the passband) in n0.part[(input*nblocks + block)*N0_SLOTS].
+__device__ __forceinline__ bool n0_bin_counts(int k, int N, N0Fuse const &n0) { // radio.c:440-447
+  int d = k - n0.start;
+  if (d < 0) d += N;
+  return d < n0.bincount;
+}
+
 template <int R, int NT>
 __global__ __launch_bounds__(NT) void kh_fft_fwd_lds(const void *__restrict__ time, size_t in_stride, int real_input,
                                                      float2 *__restrict__ spec, size_t spec_in_stride, int L,
-                                                     const float2 *__restrict__ tw) {
+                                                     const float2 *__restrict__ tw, N0Fuse n0) {
   __shared__ __attribute__((aligned(16))) float2 buf[R];
+  __shared__ float red[NT / 64 > 0 ? NT / 64 : 1];
   int const tid = threadIdx.x;
   int const b = blockIdx.x, i = blockIdx.y;
   if (real_input) {
@@ -37,106 +47,266 @@ __global__ __launch_bounds__(NT) void kh_fft_fwd_lds(const void *__restrict__ ti
   __syncthreads();
   lds_fft<R, 1, NT, 1, 1, false, -1>(buf, tw, tid);
   float4 *dst = reinterpret_cast<float4 *>(spec + i * spec_in_stride + (size_t)b * R);
-  for (int k = tid; k < R / 2; k += NT) dst[k] = reinterpret_cast<float4 *>(buf)[k];
+  float pw = 0.f;
+  for (int k = tid; k < R / 2; k += NT) {
+    float4 const v = reinterpret_cast<float4 *>(buf)[k];
+    dst[k] = v;
+    if (n0.part != nullptr) {
+      if (n0_bin_counts(2 * k, R, n0)) pw += v.x * v.x + v.y * v.y;
+      if (n0_bin_counts(2 * k + 1, R, n0)) pw += v.z * v.z + v.w * v.w;
+    }
+  }
+  if (n0.part != nullptr) { // uniform
+    pw = block_sum<NT>(pw, red);
+    if (tid == 0) n0.part[((size_t)i * gridDim.x + b) * N0_SLOTS] = pw;
+  }
 }
 
 // ================================================================ forward FFT, N = N1*N2 > 8192: four-step, two launches
 // X[k1 + N1*k2] = sum_{n2} W_N^{n2 k1} [ sum_{n1} x[n1*N2 + n2] W_N1^{n1 k1} ] W_N2^{n2 k2}
-// pass 1: 16 adjacent columns n2 per workgroup (128-byte row segments), N1-point transforms down the columns,
+// kh_fft_cols: 16 adjacent columns n2 per workgroup (128-byte row segments), N1-point transforms down the columns,
 //         four-step twiddle, result A[k1][n2] written in the input's own layout.
-// pass 2: 16 adjacent rows k1 per workgroup, N2-point transforms along the rows, transposed store.
+// kh_fft_rows: 16 adjacent rows k1 per workgroup, N2-point transforms along the rows, transposed store (128-byte
+//         segments of X), optional compute_n0 first-pass partial sum.
+// Both keep the tile in REGISTERS: an R = RA*RB point sequence is RB interleaved RA-point transforms (one per lane,
+// kh_regfft.cuh), a twiddle, ONE exchange through LDS (real parts, then imaginary parts, so the buffer is 4 bytes
+// per point: R = 512 needs 34 KiB and four workgroups share a CU), and RA interleaved RB-point transforms:
+//   X[c + RA*d] = sum_b W_RB^{b d} ( W_R^{b c} sum_a x[RB*a + b] W_RA^{a c} ).
 // algorithmic bytes per launch, each pass: nblocks*ninputs*(8N read + 8N write)
+// v[c] *= W_R^{b c}, c < RA, with W_R^{b(4q+j)} = W_R^{4bq} W_R^{bj}: RA/4 + 2 table reads per lane instead of RA - 1
+template <int RA>
+__device__ __forceinline__ void inner_twiddle(float2 (&v)[RA], const float2 *__restrict__ tw, int b) {
+  float2 const u1 = tw[b], u2 = tw[2 * b], u3 = tw[3 * b];
+  v[1] = cmul(v[1], u1);
+  v[2] = cmul(v[2], u2);
+  v[3] = cmul(v[3], u3);
+#pragma unroll
+  for (int q = 1; q < RA / 4; q++) {
+    float2 const t = tw[4 * q * b];
+    v[4 * q] = cmul(v[4 * q], t);
+    v[4 * q + 1] = cmul(v[4 * q + 1], cmul(t, u1));
+    v[4 * q + 2] = cmul(v[4 * q + 2], cmul(t, u2));
+    v[4 * q + 3] = cmul(v[4 * q + 3], cmul(t, u3));
+  }
+}
+// Strided tile accesses go through buffer instructions: ONE per-lane byte offset register serves every row of the
+// tile, the row offset (wave-uniform) travels in an SGPR.  With 64-bit flat addresses the compiler keeps one address
+// pair per outstanding load alive: 64 VGPRs for a 32-row column, which costs a workgroup per CU.
+typedef unsigned int kh_u32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void *base, unsigned bytes) { // base: wave-uniform
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(base), 0, bytes, 0x00020000);
+}
+__device__ __forceinline__ float2 buf_load2(__amdgpu_buffer_rsrc_t r, int voff, int soff) {
+  kh_u32x2 const t = __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, 0);
+  return make_float2(__uint_as_float(t.x), __uint_as_float(t.y));
+}
+__device__ __forceinline__ void buf_store2(float2 v, __amdgpu_buffer_rsrc_t r, int voff, int soff) {
+  kh_u32x2 t;
+  t.x = __float_as_uint(v.x);
+  t.y = __float_as_uint(v.y);
+  __builtin_amdgcn_raw_buffer_store_b64(t, r, voff, soff, 0);
+}
+__device__ __forceinline__ float2 big_tw(BigTwiddle const &bt, unsigned idx) { // W_N^idx, idx < N
+  return cmul(bt.coarse[idx >> 10], bt.fine[idx & 1023]);
+}
+
 constexpr int TILE_W = 16;
 
-template <int R, int NT>
-__global__ __launch_bounds__(NT) void kh_fft_pass1(const float2 *__restrict__ time, size_t in_stride,
-                                                   float2 *__restrict__ tmp, size_t spec_in_stride, int N2, int L,
-                                                   const float2 *__restrict__ tw, BigTwiddle bt) {
-  constexpr int W = TILE_W;
-  __shared__ __attribute__((aligned(16))) float2 buf[R * W];
+template <int RA, int RB, int NT>
+__global__ __launch_bounds__(NT, 4) void kh_fft_cols(const float2 *__restrict__ time, size_t in_stride,
+                                                  float2 *__restrict__ tmp, size_t spec_in_stride, int N2, int L,
+                                                  const float2 *__restrict__ tw, BigTwiddle bt) {
+  constexpr int W = TILE_W, R = RA * RB;
+  constexpr int I1 = W * RB / NT; // RA-point transforms per lane
+  constexpr int I2 = W * RA / NT; // RB-point transforms per lane
+  static_assert(I1 * NT == W * RB && I2 * NT == W * RA, "tile must divide evenly over the workgroup");
+  constexpr int CS = RB * W + 16; // pitch of c: an odd multiple of 16 floats, so two c's in a 32-lane group differ in bank
+  __shared__ float ex[RA * CS];
   int const tid = threadIdx.x;
   int const tile = blockIdx.x, b = blockIdx.y, i = blockIdx.z;
-  int const cp = tid & 7;   // column pair inside the tile
-  int const r0 = tid >> 3;
-  const float2 *src = time + i * in_stride + (size_t)b * L + tile * W + 2 * cp;
-#pragma unroll 4
-  for (int r = r0; r < R; r += NT / 8)
-    *reinterpret_cast<float4 *>(buf + r * W + 2 * cp) = *reinterpret_cast<const float4 *>(src + (size_t)r * N2);
+  unsigned const tile_bytes = (unsigned)R * (unsigned)N2 * 8u; // the block's N points (8 MiB at most)
+  __amdgpu_buffer_rsrc_t const rin = make_rsrc(time + i * in_stride + (size_t)b * L + tile * W, tile_bytes);
+  int const row_bytes = N2 * 8;
+  float2 v[I1][RA];
+  {
+    int const voff = (tid / W) * row_bytes + (tid % W) * 8; // item u: NT/W rows further down
+#pragma unroll
+    for (int u = 0; u < I1; u++)
+#pragma unroll
+      for (int a = 0; a < RA; a++) v[u][a] = buf_load2(rin, voff, (RB * a + u * (NT / W)) * row_bytes);
+  }
+#pragma unroll
+  for (int u = 0; u < I1; u++) {
+    int const bb = (tid + u * NT) / W;
+    reg_fft<RA, -1>(v[u]);
+    inner_twiddle<RA>(v[u], tw, bb);
+  }
+  // exchange: real parts, then imaginary parts, through the same 4-byte-per-point buffer
+  float zr[I2][RB], zi[I2][RB];
+#pragma unroll
+  for (int u = 0; u < I1; u++) {
+    int const item = tid + u * NT, w = item % W, bb = item / W;
+#pragma unroll
+    for (int c = 0; c < RA; c++) ex[c * CS + bb * W + w] = v[u][c].x;
+  }
   __syncthreads();
-  lds_fft<R, W, NT, W, 1, true, -1>(buf, tw, tid);
+#pragma unroll
+  for (int u = 0; u < I2; u++) {
+    int const item = tid + u * NT, w = item % W, c = item / W;
+#pragma unroll
+    for (int bb = 0; bb < RB; bb++) zr[u][bb] = ex[c * CS + bb * W + w];
+  }
+  __syncthreads();
+#pragma unroll
+  for (int u = 0; u < I1; u++) {
+    int const item = tid + u * NT, w = item % W, bb = item / W;
+#pragma unroll
+    for (int c = 0; c < RA; c++) ex[c * CS + bb * W + w] = v[u][c].y;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int u = 0; u < I2; u++) {
+    int const item = tid + u * NT, w = item % W, c = item / W;
+#pragma unroll
+    for (int bb = 0; bb < RB; bb++) zi[u][bb] = ex[c * CS + bb * W + w];
+  }
   size_t const N = (size_t)R * N2;
-  float2 *dst = tmp + i * spec_in_stride + (size_t)b * N + tile * W + 2 * cp;
-  int const n2 = tile * W + 2 * cp;
-#pragma unroll 4
-  for (int k1 = r0; k1 < R; k1 += NT / 8) {
-    float4 v = *reinterpret_cast<float4 *>(buf + k1 * W + 2 * cp);
-    unsigned const i0 = (unsigned)n2 * (unsigned)k1; // < N
-    unsigned const i1 = i0 + (unsigned)k1;
-    float2 const w0 = cmul(bt.coarse[i0 >> 10], bt.fine[i0 & 1023]);
-    float2 const w1 = cmul(bt.coarse[i1 >> 10], bt.fine[i1 & 1023]);
-    float2 const a = cmul(make_float2(v.x, v.y), w0);
-    float2 const c = cmul(make_float2(v.z, v.w), w1);
-    *reinterpret_cast<float4 *>(dst + (size_t)k1 * N2) = make_float4(a.x, a.y, c.x, c.y);
+  __amdgpu_buffer_rsrc_t const rout = make_rsrc(tmp + i * spec_in_stride + (size_t)b * N + tile * W, tile_bytes);
+#pragma unroll
+  for (int u = 0; u < I2; u++) {
+    int const item = tid + u * NT, w = item % W, c = item / W;
+    float2 z[RB];
+#pragma unroll
+    for (int bb = 0; bb < RB; bb++) z[bb] = make_float2(zr[u][bb], zi[u][bb]);
+    reg_fft<RB, -1>(z);
+    // four-step twiddle W_N^{n2 k1}, k1 = c + RA*(8q + j):  W_N^{n2 (c + 8 RA q)} W_N^{n2 RA j}  (every index < N)
+    // (scheduling fences: the compiler otherwise hoists all of the table reads above the transform and spills)
+    __builtin_amdgcn_sched_barrier(0);
+    unsigned const n2 = (unsigned)(tile * W + w);
+    float2 uj[8];
+#pragma unroll
+    for (int j = 1; j < 8; j++) uj[j] = big_tw(bt, n2 * (unsigned)(RA * j));
+#pragma unroll
+    for (int q = 0; q < RB / 8; q++) {
+      float2 const tq = big_tw(bt, n2 * (unsigned)(c + RA * 8 * q));
+#pragma unroll
+      for (int j = 0; j < 8; j++) {
+        int const d = 8 * q + j;
+        float2 const wf = j ? cmul(tq, uj[j]) : tq;
+        buf_store2(cmul(z[d], wf), rout, (c * N2 + w) * 8, RA * d * row_bytes);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
   }
 }
 
-template <int R, int NT>
-__global__ __launch_bounds__(NT) void kh_fft_pass2(const float2 *__restrict__ tmp, float2 *__restrict__ spec,
-                                                   size_t spec_in_stride, int N1, const float2 *__restrict__ tw) {
-  constexpr int W = TILE_W;
-  constexpr int SC = R + 2; // row pitch: even (16-byte rows) and bank-skewed for the transposed read
-  __shared__ __attribute__((aligned(16))) float2 buf[W * SC];
+template <int RA, int RB, int NT>
+__global__ __launch_bounds__(NT, 4) void kh_fft_rows(const float2 *__restrict__ tmp, float2 *__restrict__ spec,
+                                                  size_t spec_in_stride, int N1, const float2 *__restrict__ tw,
+                                                  N0Fuse n0) {
+  constexpr int W = TILE_W, R = RA * RB;
+  constexpr int I1 = W * RB / NT, I2 = W * RA / NT;
+  static_assert(I1 * NT == W * RB && I2 * NT == W * RA, "tile must divide evenly over the workgroup");
+  constexpr int RP = RB + 1;  // pitch of a row: odd, so the 16 rows a 32-lane group reads differ in bank
+  constexpr int CS = W * RP;  // pitch of c (an odd multiple of 16 floats)
+  __shared__ float ex[RA * CS];
+  __shared__ float red[NT / 64];
   int const tid = threadIdx.x;
   int const tile = blockIdx.x, b = blockIdx.y, i = blockIdx.z;
   size_t const N = (size_t)R * N1;
   const float2 *src = tmp + i * spec_in_stride + (size_t)b * N + (size_t)tile * W * R;
-#pragma unroll 4
-  for (int idx = tid; idx < W * R / 2; idx += NT) {
-    int const c = idx / (R / 2), j = idx % (R / 2);
-    *reinterpret_cast<float4 *>(buf + c * SC + 2 * j) = reinterpret_cast<const float4 *>(src + (size_t)c * R)[j];
+  float2 v[I1][RA];
+#pragma unroll
+  for (int u = 0; u < I1; u++) { // lanes run along the row: RB consecutive points, then the next row
+    int const item = tid + u * NT, bb = item % RB, w = item / RB;
+#pragma unroll
+    for (int a = 0; a < RA; a++) v[u][a] = src[(size_t)w * R + RB * a + bb];
+  }
+#pragma unroll
+  for (int u = 0; u < I1; u++) {
+    int const bb = (tid + u * NT) % RB;
+    reg_fft<RA, -1>(v[u]);
+    inner_twiddle<RA>(v[u], tw, bb);
+  }
+  float zr[I2][RB], zi[I2][RB];
+#pragma unroll
+  for (int u = 0; u < I1; u++) {
+    int const item = tid + u * NT, bb = item % RB, w = item / RB;
+#pragma unroll
+    for (int c = 0; c < RA; c++) ex[c * CS + w * RP + bb] = v[u][c].x;
   }
   __syncthreads();
-  lds_fft<R, W, NT, 1, SC, false, -1>(buf, tw, tid);
-  int const cp = tid & 7;
-  float2 *dst = spec + i * spec_in_stride + (size_t)b * N + tile * W + 2 * cp;
-#pragma unroll 4
-  for (int k2 = tid >> 3; k2 < R; k2 += NT / 8) {
-    float2 const a = buf[(2 * cp) * SC + k2];
-    float2 const c = buf[(2 * cp + 1) * SC + k2];
-    *reinterpret_cast<float4 *>(dst + (size_t)k2 * N1) = make_float4(a.x, a.y, c.x, c.y);
+#pragma unroll
+  for (int u = 0; u < I2; u++) { // lanes run across the 16 rows: the transposed store below is 128 bytes wide
+    int const item = tid + u * NT, w = item % W, c = item / W;
+#pragma unroll
+    for (int bb = 0; bb < RB; bb++) zr[u][bb] = ex[c * CS + w * RP + bb];
+  }
+  __syncthreads();
+#pragma unroll
+  for (int u = 0; u < I1; u++) {
+    int const item = tid + u * NT, bb = item % RB, w = item / RB;
+#pragma unroll
+    for (int c = 0; c < RA; c++) ex[c * CS + w * RP + bb] = v[u][c].y;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int u = 0; u < I2; u++) {
+    int const item = tid + u * NT, w = item % W, c = item / W;
+#pragma unroll
+    for (int bb = 0; bb < RB; bb++) zi[u][bb] = ex[c * CS + w * RP + bb];
+  }
+  __amdgpu_buffer_rsrc_t const rout = make_rsrc(spec + i * spec_in_stride + (size_t)b * N + tile * W, (unsigned)N * 8u);
+  float pw = 0.f;
+#pragma unroll
+  for (int u = 0; u < I2; u++) {
+    int const item = tid + u * NT, w = item % W, c = item / W;
+    float2 z[RB];
+#pragma unroll
+    for (int bb = 0; bb < RB; bb++) z[bb] = make_float2(zr[u][bb], zi[u][bb]);
+    reg_fft<RB, -1>(z);
+#pragma unroll
+    for (int d = 0; d < RB; d++) {
+      int const k2 = c + RA * d;
+      float2 const x = z[d];
+      buf_store2(x, rout, (c * N1 + w) * 8, RA * d * N1 * 8); // X[k1 + N1*k2], k1 = tile*W + w
+      if (n0.part != nullptr && n0_bin_counts(tile * W + w + N1 * k2, (int)N, n0)) pw += x.x * x.x + x.y * x.y;
+    }
+  }
+  if (n0.part != nullptr) { // uniform
+    pw = block_sum<NT>(pw, red);
+    if (tid == 0) n0.part[((size_t)i * gridDim.y + b) * N0_SLOTS + tile] = pw;
   }
 }
 
 template <int R>
 static int launch_small(hipStream_t st, const void *time, size_t in_stride, int real_input, float2 *spec,
-                        size_t spec_in_stride, int L, int nblocks, int ninputs) {
+                        size_t spec_in_stride, int L, int nblocks, int ninputs, N0Fuse n0) {
   constexpr int NT = (R / 4 < 256) ? R / 4 : 256;
   const float2 *tw = twiddle_table(R);
   if (!tw) return -1;
   hipLaunchKernelGGL((kh_fft_fwd_lds<R, NT>), dim3(nblocks, ninputs), dim3(NT), 0, st, time, in_stride, real_input, spec,
-                     spec_in_stride, L, tw);
+                     spec_in_stride, L, tw, n0);
   return KH_HIP(hipGetLastError()) ? 0 : -1;
 }
 
-template <int R>
-static int launch_p1(hipStream_t st, const float2 *time, size_t in_stride, float2 *tmp, size_t spec_in_stride, int N2,
-                     int L, int nblocks, int ninputs) {
-  constexpr int NT = R / 2;
-  const float2 *tw = twiddle_table(R);
-  BigTwiddle bt = big_twiddle(R * N2);
+template <int RA, int RB, int NT>
+static int launch_cols(hipStream_t st, const float2 *time, size_t in_stride, float2 *tmp, size_t spec_in_stride, int N2,
+                       int L, int nblocks, int ninputs) {
+  const float2 *tw = twiddle_table(RA * RB);
+  BigTwiddle bt = big_twiddle(RA * RB * N2);
   if (!tw || !bt.fine) return -1;
-  hipLaunchKernelGGL((kh_fft_pass1<R, NT>), dim3(N2 / TILE_W, nblocks, ninputs), dim3(NT), 0, st, time, in_stride, tmp,
-                     spec_in_stride, N2, L, tw, bt);
+  hipLaunchKernelGGL((kh_fft_cols<RA, RB, NT>), dim3(N2 / TILE_W, nblocks, ninputs), dim3(NT), 0, st, time, in_stride,
+                     tmp, spec_in_stride, N2, L, tw, bt);
   return KH_HIP(hipGetLastError()) ? 0 : -1;
 }
-template <int R>
-static int launch_p2(hipStream_t st, const float2 *tmp, float2 *spec, size_t spec_in_stride, int N1, int nblocks,
-                     int ninputs) {
-  constexpr int NT = R / 2;
-  const float2 *tw = twiddle_table(R);
+template <int RA, int RB, int NT>
+static int launch_rows(hipStream_t st, const float2 *tmp, float2 *spec, size_t spec_in_stride, int N1, int nblocks,
+                       int ninputs, N0Fuse n0) {
+  const float2 *tw = twiddle_table(RA * RB);
   if (!tw) return -1;
-  hipLaunchKernelGGL((kh_fft_pass2<R, NT>), dim3(N1 / TILE_W, nblocks, ninputs), dim3(NT), 0, st, tmp, spec,
-                     spec_in_stride, N1, tw);
+  hipLaunchKernelGGL((kh_fft_rows<RA, RB, NT>), dim3(N1 / TILE_W, nblocks, ninputs), dim3(NT), 0, st, tmp, spec,
+                     spec_in_stride, N1, tw, n0);
   return KH_HIP(hipGetLastError()) ? 0 : -1;
 }
 
@@ -146,8 +316,14 @@ static int ilog2(unsigned v) {
   return e;
 }
 
+int n0_partials(int N) { // first-pass partial sums the forward transform leaves per (input, block)
+  if (N <= KH_MAX_SMALL_N) return 1;
+  int const e = ilog2((unsigned)N);
+  return (1 << ((e + 1) / 2)) / TILE_W;
+}
+
 int launch_forward_fft(hipStream_t st, const void *time, size_t in_stride, int real_input, float2 *spec, float2 *tmp,
-                       size_t spec_in_stride, int N, int L, int nblocks, int ninputs, hipEvent_t mid_event) {
+                       size_t spec_in_stride, int N, int L, int nblocks, int ninputs, hipEvent_t mid_event, N0Fuse n0) {
   if (N < 256 || (N & (N - 1)) || N > (1 << 20)) {
     set_error("forward FFT size %d unsupported (power of two in [256, 2^20] required)", N);
     return -1;
@@ -156,12 +332,12 @@ int launch_forward_fft(hipStream_t st, const void *time, size_t in_stride, int r
   if (N <= KH_MAX_SMALL_N) {
     int rc = -1;
     switch (N) {
-    case 256: rc = launch_small<256>(st, time, in_stride, real_input, spec, spec_in_stride, L, nblocks, ninputs); break;
-    case 512: rc = launch_small<512>(st, time, in_stride, real_input, spec, spec_in_stride, L, nblocks, ninputs); break;
-    case 1024: rc = launch_small<1024>(st, time, in_stride, real_input, spec, spec_in_stride, L, nblocks, ninputs); break;
-    case 2048: rc = launch_small<2048>(st, time, in_stride, real_input, spec, spec_in_stride, L, nblocks, ninputs); break;
-    case 4096: rc = launch_small<4096>(st, time, in_stride, real_input, spec, spec_in_stride, L, nblocks, ninputs); break;
-    case 8192: rc = launch_small<8192>(st, time, in_stride, real_input, spec, spec_in_stride, L, nblocks, ninputs); break;
+    case 256: rc = launch_small<256>(st, time, in_stride, real_input, spec, spec_in_stride, L, nblocks, ninputs, n0); break;
+    case 512: rc = launch_small<512>(st, time, in_stride, real_input, spec, spec_in_stride, L, nblocks, ninputs, n0); break;
+    case 1024: rc = launch_small<1024>(st, time, in_stride, real_input, spec, spec_in_stride, L, nblocks, ninputs, n0); break;
+    case 2048: rc = launch_small<2048>(st, time, in_stride, real_input, spec, spec_in_stride, L, nblocks, ninputs, n0); break;
+    case 4096: rc = launch_small<4096>(st, time, in_stride, real_input, spec, spec_in_stride, L, nblocks, ninputs, n0); break;
+    case 8192: rc = launch_small<8192>(st, time, in_stride, real_input, spec, spec_in_stride, L, nblocks, ninputs, n0); break;
     }
     if (mid_event) hipEventRecord(mid_event, st);
     return rc;
@@ -170,27 +346,23 @@ int launch_forward_fft(hipStream_t st, const void *time, size_t in_stride, int r
     set_error("REAL input is limited to N <= %d", KH_MAX_SMALL_N);
     return -1;
   }
-  if (L % 2) {
-    set_error("L must be even for N > %d", KH_MAX_SMALL_N);
-    return -1;
-  }
   int const e = ilog2((unsigned)N);
   int const N1 = 1 << ((e + 1) / 2), N2 = 1 << (e / 2);
   const float2 *t = static_cast<const float2 *>(time);
   int rc = -1;
   switch (N1) {
-  case 128: rc = launch_p1<128>(st, t, in_stride, tmp, spec_in_stride, N2, L, nblocks, ninputs); break;
-  case 256: rc = launch_p1<256>(st, t, in_stride, tmp, spec_in_stride, N2, L, nblocks, ninputs); break;
-  case 512: rc = launch_p1<512>(st, t, in_stride, tmp, spec_in_stride, N2, L, nblocks, ninputs); break;
-  case 1024: rc = launch_p1<1024>(st, t, in_stride, tmp, spec_in_stride, N2, L, nblocks, ninputs); break;
+  case 128: rc = launch_cols<8, 16, 128>(st, t, in_stride, tmp, spec_in_stride, N2, L, nblocks, ninputs); break;
+  case 256: rc = launch_cols<16, 16, 256>(st, t, in_stride, tmp, spec_in_stride, N2, L, nblocks, ninputs); break;
+  case 512: rc = launch_cols<16, 32, 256>(st, t, in_stride, tmp, spec_in_stride, N2, L, nblocks, ninputs); break;
+  case 1024: rc = launch_cols<32, 32, 512>(st, t, in_stride, tmp, spec_in_stride, N2, L, nblocks, ninputs); break;
   }
   if (rc) return rc;
   if (mid_event) hipEventRecord(mid_event, st);
   switch (N2) {
-  case 128: rc = launch_p2<128>(st, tmp, spec, spec_in_stride, N1, nblocks, ninputs); break;
-  case 256: rc = launch_p2<256>(st, tmp, spec, spec_in_stride, N1, nblocks, ninputs); break;
-  case 512: rc = launch_p2<512>(st, tmp, spec, spec_in_stride, N1, nblocks, ninputs); break;
-  case 1024: rc = launch_p2<1024>(st, tmp, spec, spec_in_stride, N1, nblocks, ninputs); break;
+  case 128: rc = launch_rows<8, 16, 128>(st, tmp, spec, spec_in_stride, N1, nblocks, ninputs, n0); break;
+  case 256: rc = launch_rows<16, 16, 256>(st, tmp, spec, spec_in_stride, N1, nblocks, ninputs, n0); break;
+  case 512: rc = launch_rows<16, 32, 256>(st, tmp, spec, spec_in_stride, N1, nblocks, ninputs, n0); break;
+  case 1024: rc = launch_rows<32, 32, 512>(st, tmp, spec, spec_in_stride, N1, nblocks, ninputs, n0); break;
   default: rc = -1;
   }
   return rc;

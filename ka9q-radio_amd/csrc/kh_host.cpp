@@ -335,7 +335,7 @@ int execute_filter_input(struct filter_in *master) {
     return -1;
   unsigned const next = master->blocknum + 1;
   float2 *spec = im->d_spec[next & 1];
-  if (launch_forward_fft(im->stream, dt, 0, im->real, spec, im->d_tmp, 0, N, L, 1, 1, nullptr)) return -1;
+  if (launch_forward_fft(im->stream, dt, 0, im->real, spec, im->d_tmp, 0, N, L, 1, 1, nullptr, N0Fuse{nullptr, 0, 0})) return -1;
   // overlap-save history for the next block (filter.c:230), on the device copy ...
   if (launch_carry(im->stream, dt + (size_t)L * im->esize, im->d_time[im->cur ^ 1], 0, (size_t)(M - 1) * im->esize, 1))
     return -1;

@@ -89,8 +89,16 @@ struct DemodState {   // one per channel, device resident, carried from launch t
 // forward transform of `nblocks` overlapping blocks per input.  time: cf32 (or f32 when real_input) stream,
 // block b of input i starts at time + i*in_stride + b*L (elements).  spec: i*spec_in_stride + b*N.
 // tmp: scratch of the same size as spec (only used when N > KH_MAX_SMALL_N).
+// n0: the epilogue of the last pass also leaves compute_n0's first-iteration partial sums (radio.c:450-461):
+// n0_partials(N) floats per (input, block) at n0.part + (input*nblocks + block)*N0_SLOTS.  n0.part == nullptr: none.
+constexpr int N0_SLOTS = 64;
+struct N0Fuse {
+  float *part;
+  int start, bincount; // radio.c:440-447: bins (start + n) mod N, n < bincount
+};
+int n0_partials(int N);
 int launch_forward_fft(hipStream_t st, const void *time, size_t in_stride, int real_input, float2 *spec, float2 *tmp,
-                       size_t spec_in_stride, int N, int L, int nblocks, int ninputs, hipEvent_t mid_event);
+                       size_t spec_in_stride, int N, int L, int nblocks, int ninputs, hipEvent_t mid_event, N0Fuse n0);
 // bin-select x response x inverse transform.  out: cf32 (or f32 when out_type REAL) at
 // out + ch*out_stride + b*olen.
 int launch_filter_output(hipStream_t st, const float2 *spec, size_t spec_in_stride, int N, int in_real,
@@ -101,10 +109,17 @@ int launch_filter_output(hipStream_t st, const float2 *spec, size_t spec_in_stri
 // energy_part: ingest_chunks(L) floats per (input, block), summed by launch_n0
 int ingest_chunks(int L);
 int n0_part_floats();
+// hist_dst (may be null): the other time buffer; samples n >= hist_from of the launch are also stored at its head
 int launch_ingest(hipStream_t st, const void *raw, size_t raw_stride_bytes, int payload, float2 *time, size_t time_stride,
-                  const IngestDesc *desc, float *energy_part, int L, int nblocks, int ninputs);
-// radio.c:422-465 + 197-202
-int launch_n0(hipStream_t st, const float2 *spec, size_t spec_in_stride, int N, int samprate, float low, float high,
+                  const IngestDesc *desc, float *energy_part, int L, int nblocks, int ninputs, float2 *hist_dst,
+                  size_t hist_from);
+// radio.c:422-465 + 197-202.  n0_plan: the bin range of radio.c:430-447; launch_n0: second iteration, smoothing and
+// IF power (the first iteration's partial sums come from launch_forward_fft)
+struct N0Plan {
+  int valid, start, bincount;
+};
+N0Plan n0_plan(int N, int samprate, float low, float high);
+int launch_n0(hipStream_t st, const float2 *spec, size_t spec_in_stride, int N, int samprate, N0Plan plan,
               const float *energy_part, int L, float *n0_state, float *part /*n0_part_floats() per (input,block)*/,
               void *input_status, int nblocks, int ninputs);
 // demodulators + scaleclip
