@@ -102,7 +102,9 @@ def main():
     ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
+    ap.add_argument("--blocks", type=int, default=T, help="blocks per step (per kh_bank_execute call)")
     args = ap.parse_args()
+    globals()["T"] = args.blocks
 
     import torch
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -127,6 +129,7 @@ def main():
 
     bank = pyka9q.Bank(L, M, D, 1, C, T, FS, payload=pyka9q.KH_PT_CF32, compute_n0=1, n0_low=-5500.0, n0_high=5500.0)
     bank.keep_audio(0)
+    bank.keep_baseband(0)  # FM: filter output -> discriminator inside one kernel; PCM + status are the outputs
     for c, r in enumerate(rots):
         bank.set_channel(c, demod=pyka9q.KH_DEMOD_FM, rotate=r, low=-5500.0, high=5500.0, kaiser_beta=3.0)
     bank.write_input_device(0, x.data_ptr(), T * L)  # device -> device; the ring now holds the step's samples

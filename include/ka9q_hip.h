@@ -214,6 +214,13 @@ int kh_bank_read_response(kh_bank *, unsigned int ch, kh_cf32 *out, float *noise
 int kh_bank_pcm_device_ptr(kh_bank *, void **dptr, size_t *words_per_channel);
 /* 1 (default): also keep the float audio that scaleclip consumed (kh_bank_read_audio); 0: PCM only */
 int kh_bank_keep_audio(kh_bank *, int enable);
+/* 1 (default): FM channels also store their complex baseband (kh_bank_read_baseband); 0: they go from the filter
+ * output straight to the discriminator inside one kernel and only PCM + status leave it.  Channels with another
+ * demodulator (or none) always store it. */
+int kh_bank_keep_baseband(kh_bank *, int enable);
+/* 1 (default): the kernel sequence of kh_bank_execute is captured into a hipGraph the second time a launch shape
+ * (nblocks, buffer parity) is seen and replayed from then on: one host call per launch.  0: plain launches. */
+int kh_bank_use_graph(kh_bank *, int enable);
 void *kh_bank_stream(kh_bank *); /* hipStream_t */
 /* per-kernel timing with HIP events on the bank's stream.  Stages: */
 enum kh_stage { KH_STAGE_INGEST = 0, KH_STAGE_FFT1, KH_STAGE_FFT2, KH_STAGE_N0, KH_STAGE_CHAN, KH_STAGE_DEMOD,

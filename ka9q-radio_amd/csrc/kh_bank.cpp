@@ -56,6 +56,8 @@ struct kh_bank {
   kh_bank_config cfg;
   int N, ND, olen, T, C, P;
   hipStream_t stream = nullptr;
+  hipStream_t side = nullptr;             // compute_n0's second iteration runs here, beside the channel kernels
+  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   // device
   unsigned char *d_raw = nullptr;
   size_t raw_stride = 0; // bytes per input
@@ -69,6 +71,10 @@ struct kh_bank {
   DemodDesc *d_ddesc = nullptr;
   DemodState *d_dstate = nullptr;
   IngestDesc *d_idesc = nullptr;
+  static constexpr int IDESC_SLOTS = 4;   // pinned staging ring for the per-launch oscillator snapshot
+  IngestDesc *h_idesc = nullptr;
+  hipEvent_t idesc_ev[IDESC_SLOTS] = {};
+  int idesc_slot = 0;
   float2 *d_bb = nullptr;
   size_t bb_stride = 0; // T*olen
   float *d_audio = nullptr;
@@ -78,9 +84,9 @@ struct kh_bank {
   kh_input_status *d_istatus = nullptr;
   float *d_energy = nullptr, *d_n0acc = nullptr, *d_n0state = nullptr, *d_scalar = nullptr;
   int *d_lists = nullptr; // fm | linear | am, C entries each
-  void *d_fmstat = nullptr, *d_fmwork = nullptr; // FM path scratch (kh_demod_kernels.hip)
+  FmBlockStat *d_fmstat = nullptr; // FM path scratch (kh_internal.h)
+  FmWork *d_fmwork = nullptr;
   double *d_fmcarry = nullptr, *d_decaypow = nullptr;
-  float *d_fmavgf = nullptr;
   int fm_parity = 0;
   // host
   std::vector<ChanDesc> chans;
@@ -94,7 +100,16 @@ struct kh_bank {
   int n_fm = 0, n_lin = 0, n_am = 0;
   bool chans_dirty = true;
   unsigned last_blocks = 0;
-  int keep_audio = 1;
+  int keep_audio = 1, keep_baseband = 1;
+  // hipGraph cache: the kernel sequence of one execute call, captured the second time a shape is seen
+  struct GraphEntry {
+    unsigned nblocks;
+    int cur, fmpar;
+    int seen;              // launches seen with this key; -1: capture failed, stay eager
+    hipGraphExec_t exec;
+  };
+  std::vector<GraphEntry> graphs;
+  int use_graph = 1, use_side = 1;
   // profiling
   bool profiling = false;
   hipEvent_t ev[KH_STAGE_COUNT + 2] = {};
@@ -104,19 +119,33 @@ struct kh_bank {
 
 static bool is_pow2(unsigned v) { return v && !(v & (v - 1)); }
 
+static void drop_graphs(kh_bank *b) { // anything a captured launch baked in has changed
+  for (auto &g : b->graphs)
+    if (g.exec) hipGraphExecDestroy(g.exec);
+  b->graphs.clear();
+}
+
 extern "C" {
 
 int kh_bank_destroy(kh_bank *b) {
   if (!b) return 0;
   if (b->stream) hipStreamSynchronize(b->stream);
+  if (b->side) hipStreamSynchronize(b->side);
+  drop_graphs(b);
   void *ptrs[] = {b->d_raw,   b->d_time[0], b->d_time[1], b->d_spec,   b->d_tmp,    b->d_chans,  b->d_resp,
                   b->d_ddesc, b->d_dstate,  b->d_idesc,   b->d_bb,     b->d_audio,  b->d_pcm,    b->d_status,
                   b->d_istatus, b->d_energy, b->d_n0acc,  b->d_n0state, b->d_scalar, b->d_lists,
-                  b->d_fmstat, b->d_fmwork, b->d_fmcarry, b->d_decaypow, b->d_fmavgf};
+                  b->d_fmstat, b->d_fmwork, b->d_fmcarry, b->d_decaypow};
   for (void *p : ptrs)
     if (p) hipFree(p);
   for (auto &e : b->ev)
     if (e) hipEventDestroy(e);
+  for (auto &e : b->idesc_ev)
+    if (e) hipEventDestroy(e);
+  if (b->h_idesc) hipHostFree(b->h_idesc);
+  if (b->ev_fork) hipEventDestroy(b->ev_fork);
+  if (b->ev_join) hipEventDestroy(b->ev_join);
+  if (b->side) hipStreamDestroy(b->side);
   if (b->stream) hipStreamDestroy(b->stream);
   delete b;
   return 0;
@@ -161,6 +190,11 @@ kh_bank *kh_bank_create(const struct kh_bank_config *cfg) {
   b->P = cfg->n_inputs;
   size_t const T = b->T, C = b->C, P = b->P, L = cfg->L, M = cfg->M;
   bool ok = KH_HIP(hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking));
+  ok = ok && KH_HIP(hipStreamCreateWithFlags(&b->side, hipStreamNonBlocking));
+  ok = ok && KH_HIP(hipHostMalloc((void **)&b->h_idesc, kh_bank::IDESC_SLOTS * P * sizeof(IngestDesc), hipHostMallocDefault));
+  for (auto &e : b->idesc_ev) ok = ok && KH_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+  ok = ok && KH_HIP(hipEventCreateWithFlags(&b->ev_fork, hipEventDisableTiming));
+  ok = ok && KH_HIP(hipEventCreateWithFlags(&b->ev_join, hipEventDisableTiming));
   b->raw_stride = (payload_bytes(cfg->payload, T * L) + 15) & ~(size_t)15;
   b->time_stride = ((M - 1) + T * L + 1) & ~(size_t)1;
   b->spec_stride = T * N;
@@ -191,10 +225,9 @@ kh_bank *kh_bank_create(const struct kh_bank_config *cfg) {
   A(&b->d_n0state, P * sizeof(float), false);
   A(&b->d_scalar, sizeof(float), true);
   A(&b->d_lists, 3 * C * sizeof(int), true);
-  A(&b->d_fmstat, C * T * 16, true);
-  A(&b->d_fmwork, C * b->bb_stride * 8, true);
+  A(&b->d_fmstat, C * T * sizeof(FmBlockStat), true);
+  A(&b->d_fmwork, C * b->bb_stride * sizeof(FmWork), true);
   A(&b->d_fmcarry, C * T * sizeof(double), true);
-  A(&b->d_fmavgf, C * T * sizeof(float), true);
   A(&b->d_decaypow, (b->olen + 1) * sizeof(double), false);
   for (auto &e : b->ev)
     if (ok) ok = KH_HIP(hipEventCreate(&e));
@@ -215,6 +248,8 @@ kh_bank *kh_bank_create(const struct kh_bank_config *cfg) {
     kh_bank_destroy(b);
     return nullptr;
   }
+  if (const char *e = getenv("KA9Q_HIP_GRAPH")) b->use_graph = atoi(e);
+  if (const char *e = getenv("KA9Q_HIP_SIDE")) b->use_side = atoi(e);
   b->chans.assign(C, ChanDesc{0, 0, COMPLEX, 0});
   b->ddesc.assign(C, DemodDesc{});
   b->ccfg.assign(C, kh_channel_config{});
@@ -318,6 +353,7 @@ int kh_bank_set_channel(kh_bank *b, unsigned int ch, const struct kh_channel_con
   if (!KH_HIP(hipMemcpyAsync(b->d_dstate + ch, &s, sizeof(s), hipMemcpyHostToDevice, st))) return -1;
   if (!KH_HIP(hipStreamSynchronize(st))) return -1;
   b->chans_dirty = true;
+  drop_graphs(b);
   return 0;
 }
 
@@ -402,36 +438,12 @@ static int upload_channels(kh_bank *b) {
   return ok ? 0 : -1;
 }
 
-int kh_bank_execute(kh_bank *b, unsigned int nblocks) {
-  if (!b) return -1;
-  if (nblocks == 0 || nblocks > (unsigned)b->T) {
-    set_error("kh_bank_execute: nblocks %u outside [1, %d]", nblocks, b->T);
-    return -1;
-  }
-  if (ensure_init()) return -1;
+// the kernel sequence of one execute call: everything between the oscillator snapshot and the ring bookkeeping.
+// Runs eagerly, or under stream capture when kh_bank_execute builds the hipGraph of this shape.
+static int enqueue(kh_bank *b, unsigned int nblocks, bool prof) {
   int const L = b->cfg.L, M = b->cfg.M, N = b->N, P = b->P, C = b->C;
   size_t const need = (size_t)nblocks * L;
-  for (int i = 0; i < P; i++)
-    if (b->fill[i] < need) {
-      set_error("kh_bank_execute: input %d holds %zu samples, %zu needed", i, b->fill[i], need);
-      return -1;
-    }
-  if (b->chans_dirty && upload_channels(b)) return -1;
   hipStream_t st = b->stream;
-  // oscillator snapshot for this launch
-  std::vector<IngestDesc> id(P);
-  for (int i = 0; i < P; i++) {
-    HostOsc &lo = b->lo2[i], &dp = b->doppler[i];
-    id[i].gain_factor = b->gain[i];
-    id[i].lo2 = NcoArgs{lo.phase, lo.freq_now, lo.rate, !(lo.freq_now == 0 && lo.rate == 0 && lo.phase == 0), 0};
-    id[i].doppler = NcoArgs{dp.phase, dp.freq_now, dp.rate, dp.freq_set != 0, 0}; // radio.c:180
-    lo.advance(need);
-    if (dp.freq_set != 0) dp.advance(need);
-  }
-  if (!KH_HIP(hipMemcpyAsync(b->d_idesc, id.data(), P * sizeof(IngestDesc), hipMemcpyHostToDevice, st))) return -1;
-  if (!KH_HIP(hipStreamSynchronize(st))) return -1; // id goes out of scope
-
-  bool const prof = b->profiling;
   int e = 0;
   auto mark = [&]() {
     if (prof) hipEventRecord(b->ev[e], st);
@@ -454,26 +466,107 @@ int kh_bank_execute(kh_bank *b, unsigned int nblocks) {
     return -1;
   e = 3;
   mark(); // 3
-  if (launch_n0(st, b->cfg.compute_n0 ? b->d_spec : nullptr, b->spec_stride, N, b->cfg.samprate, plan, b->d_energy, L,
+  // compute_n0's second iteration and the smoothing only read the spectrum: they run on the side stream while the
+  // channel kernels run on this one (joined below).  With per-stage timing on, everything stays on one stream.
+  bool const fork = !prof && b->use_side;
+  hipStream_t const sn = fork ? b->side : st;
+  if (fork && (!KH_HIP(hipEventRecord(b->ev_fork, st)) || !KH_HIP(hipStreamWaitEvent(sn, b->ev_fork, 0)))) return -1;
+  if (launch_n0(sn, b->cfg.compute_n0 ? b->d_spec : nullptr, b->spec_stride, N, b->cfg.samprate, plan, b->d_energy, L,
                 b->d_n0state, b->d_n0acc, b->d_istatus, nblocks, P))
     return -1;
+  if (fork && !KH_HIP(hipEventRecord(b->ev_join, sn))) return -1;
   mark(); // 4
   if (launch_filter_output(st, b->d_spec, b->spec_stride, N, 0, b->d_chans, b->d_resp, b->ND, b->olen, b->d_bb,
-                           b->bb_stride, nblocks, C, b->d_fmstat, b->T))
+                           b->bb_stride, nblocks, C,
+                           FmFront{b->n_fm ? b->d_fmstat : nullptr, b->d_fmwork, b->d_fmcarry, b->d_ddesc, b->T, b->bb_stride,
+                                   b->keep_baseband}))
     return -1;
   mark(); // 5
   if (launch_demod(st, b->d_bb, b->bb_stride, b->olen, nblocks, C, b->d_ddesc, b->d_dstate,
                    b->keep_audio ? b->d_audio : nullptr, b->d_pcm, b->pcm_stride, b->cfg.pcm_big_endian, b->d_status,
                    b->T, b->d_lists, b->n_fm, b->d_lists + C, b->n_lin, b->d_lists + 2 * C, b->n_am,
-                   FmScratch{b->d_fmstat, b->d_fmwork, b->d_fmcarry, b->d_fmavgf, b->d_decaypow, b->fm_parity}))
+                   FmScratch{b->d_fmstat, b->d_fmwork, b->d_fmcarry, b->d_decaypow, b->fm_parity}))
     return -1;
-  if (b->n_fm) b->fm_parity ^= 1;
   mark(); // 6
   // overlap-save history for the next call (filter.c:230), into the other buffer
   if (!fused_carry && launch_carry(st, time + need, b->d_time[b->cur ^ 1], b->time_stride * sizeof(float2),
                                    (size_t)(M - 1) * sizeof(float2), P))
     return -1;
   mark(); // 7
+  if (fork && !KH_HIP(hipStreamWaitEvent(st, b->ev_join, 0))) return -1;
+  return 0;
+}
+
+int kh_bank_execute(kh_bank *b, unsigned int nblocks) {
+  if (!b) return -1;
+  if (nblocks == 0 || nblocks > (unsigned)b->T) {
+    set_error("kh_bank_execute: nblocks %u outside [1, %d]", nblocks, b->T);
+    return -1;
+  }
+  if (ensure_init()) return -1;
+  int const L = b->cfg.L, P = b->P;
+  size_t const need = (size_t)nblocks * L;
+  for (int i = 0; i < P; i++)
+    if (b->fill[i] < need) {
+      set_error("kh_bank_execute: input %d holds %zu samples, %zu needed", i, b->fill[i], need);
+      return -1;
+    }
+  if (b->chans_dirty && upload_channels(b)) return -1;
+  hipStream_t st = b->stream;
+  // oscillator snapshot for this launch, staged through a pinned ring so that the host never waits for the device
+  int const slot = b->idesc_slot;
+  b->idesc_slot = (slot + 1) % kh_bank::IDESC_SLOTS;
+  if (!KH_HIP(hipEventSynchronize(b->idesc_ev[slot]))) return -1; // the copy that last used this slot (long done)
+  IngestDesc *id = b->h_idesc + (size_t)slot * P;
+  for (int i = 0; i < P; i++) {
+    HostOsc &lo = b->lo2[i], &dp = b->doppler[i];
+    id[i].gain_factor = b->gain[i];
+    id[i].lo2 = NcoArgs{lo.phase, lo.freq_now, lo.rate, !(lo.freq_now == 0 && lo.rate == 0 && lo.phase == 0), 0};
+    id[i].doppler = NcoArgs{dp.phase, dp.freq_now, dp.rate, dp.freq_set != 0, 0}; // radio.c:180
+    lo.advance(need);
+    if (dp.freq_set != 0) dp.advance(need);
+  }
+  if (!KH_HIP(hipMemcpyAsync(b->d_idesc, id, P * sizeof(IngestDesc), hipMemcpyHostToDevice, st))) return -1;
+  if (!KH_HIP(hipEventRecord(b->idesc_ev[slot], st))) return -1;
+
+  bool const prof = b->profiling;
+  int rc = 0;
+  if (prof || !b->use_graph) {
+    rc = enqueue(b, nblocks, prof);
+  } else {
+    kh_bank::GraphEntry *g = nullptr;
+    for (auto &x : b->graphs)
+      if (x.nblocks == nblocks && x.cur == b->cur && x.fmpar == b->fm_parity) g = &x;
+    if (!g) { // first sight: run eagerly (this also warms the twiddle tables, which allocate)
+      b->graphs.push_back(kh_bank::GraphEntry{nblocks, b->cur, b->fm_parity, 1, nullptr});
+      rc = enqueue(b, nblocks, false);
+    } else if (g->seen < 0) {
+      rc = enqueue(b, nblocks, false);
+    } else {
+      if (!g->exec) {
+        hipGraph_t graph = nullptr;
+        bool ok = KH_HIP(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
+        if (ok) {
+          int const erc = enqueue(b, nblocks, false);
+          ok = KH_HIP(hipStreamEndCapture(st, &graph)) && erc == 0 && graph != nullptr;
+        }
+        if (ok) ok = KH_HIP(hipGraphInstantiate(&g->exec, graph, nullptr, nullptr, 0));
+        if (graph) hipGraphDestroy(graph);
+        if (!ok) {
+          g->exec = nullptr;
+          g->seen = -1;
+        }
+      }
+      if (g->exec) {
+        g->seen++;
+        rc = KH_HIP(hipGraphLaunch(g->exec, st)) ? 0 : -1;
+      } else {
+        rc = enqueue(b, nblocks, false);
+      }
+    }
+  }
+  if (rc) return rc;
+  if (b->n_fm) b->fm_parity ^= 1;
   b->cur ^= 1;
   // consume the raw ring
   for (int i = 0; i < P; i++) {
@@ -557,6 +650,19 @@ void *kh_bank_stream(kh_bank *b) { return b ? (void *)b->stream : nullptr; }
 int kh_bank_keep_audio(kh_bank *b, int enable) {
   if (!b) return -1;
   b->keep_audio = enable != 0;
+  drop_graphs(b);
+  return 0;
+}
+int kh_bank_keep_baseband(kh_bank *b, int enable) {
+  if (!b) return -1;
+  b->keep_baseband = enable != 0;
+  drop_graphs(b);
+  return 0;
+}
+int kh_bank_use_graph(kh_bank *b, int enable) {
+  if (!b) return -1;
+  b->use_graph = enable != 0;
+  if (!enable) drop_graphs(b);
   return 0;
 }
 int kh_bank_profile(kh_bank *b, int enable) {

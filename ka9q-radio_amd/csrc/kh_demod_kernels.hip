@@ -285,22 +285,17 @@ __device__ __forceinline__ short pcm_word(float x, int big_endian) {
   return (short)(unsigned short)((u << 8) | (u >> 8)); // htons, audio.c:50,101
 }
 
-// ================================================================ FM: fm.c:43-139 in three parallel steps
-//  (1) kh_filter_out's epilogue leaves bb_power, fm_variance and the Rice-corrected SNR of every block
-//      (fm.c:53-70) in FmBlockStat.
-//  (2) kh_fm_disc, one workgroup per (channel, block): squelch decision, conjugate-product discriminator,
-//      threshold-extension weight, and the de-emphasis integrator run from a ZERO carry-in.
-//  (3) kh_fm_finish, one workgroup per (channel, block): folds the carries of the earlier blocks
-//      (s_n = s0_n + carry * decay^k, exact by linearity of fm.c:110-111), scaleclip, output level,
-//      frequency offset and the order-dependent peak-deviation update of fm.c:97-102.
-// The squelch (fm.c:73-78) looks back at most one block (squelch_open = 2 spans two blocks), so every
-// workgroup replays it from the per-block SNRs without talking to its neighbours.
+// ================================================================ FM: fm.c:43-139 in two parallel steps
+//  (1) kh_filter_out's epilogue (fm_front, kh_fm.cuh), one workgroup per (channel, block), while the block is still
+//      in LDS: bb_power, fm_variance and the Rice-corrected SNR (fm.c:53-70); the conjugate-product discriminator
+//      and threshold-extension weight of samples 1.. (fm.c:85-93); the de-emphasis integrator run from a ZERO
+//      carry-in (fm.c:110-111).  Nothing in it depends on another block.
+//  (2) kh_fm_finish, one workgroup per (channel, block): the squelch (fm.c:73-78, which looks back at most one
+//      block, so every workgroup replays it from the per-block SNRs); sample 0's discriminator output, which needs
+//      the last sample of the block before; the carries of the earlier blocks folded in (s_n = s0_n + carry *
+//      decay^n, exact by linearity of fm.c:110-111); scaleclip, output level, frequency offset and the
+//      order-dependent peak-deviation update of fm.c:97-102.
 constexpr int FMB_NT = 256;
-constexpr double FM_DECAY = 0.99376949; // fm.c:111,130
-
-struct FmWork { // per sample, between kh_fm_disc and kh_fm_finish
-  float ang, s0;
-};
 
 // fm.c:73-78 in closed form.  `squelch_open = 2` spans two blocks and is decremented once per open block, so
 // after block j the counter is 1 if snr_j > 4, else max(counter_{j-1} - 1, 0), which is 0 for every j >= 1
@@ -312,144 +307,36 @@ __device__ __forceinline__ int fm_counter_after(const FmBlockStat *__restrict__ 
   if (j == 0) return so_in - 1 > 0 ? so_in - 1 : 0;
   return 0;
 }
-__device__ __forceinline__ void fm_squelch(const FmBlockStat *__restrict__ fs, int b, int so_in, int &open_b,
-                                           int &open_prev, int &so_out) {
-  int const before = fm_counter_after(fs, b - 1, so_in);
-  open_b = fs[b].snr > 4.f || before > 0;
-  so_out = fm_counter_after(fs, b, so_in);
-  open_prev = 0;
-  if (b > 0) open_prev = fs[b - 1].snr > 4.f || fm_counter_after(fs, b - 2, so_in) > 0;
+__device__ __forceinline__ int fm_is_open(const FmBlockStat *__restrict__ fs, int j, int so_in) {
+  return fs[j].snr > 4.f || fm_counter_after(fs, j - 1, so_in) > 0;
 }
-
-// algorithmic bytes per (channel, block): 8*olen baseband read + 8*olen work written
-__global__ __launch_bounds__(FMB_NT) void kh_fm_disc(const float2 *__restrict__ baseband, size_t bb_stride, int olen,
-                                                     const DemodDesc *__restrict__ descs,
-                                                     const DemodState *__restrict__ states, int par,
-                                                     const FmBlockStat *__restrict__ fmstat, int stat_stride,
-                                                     FmWork *__restrict__ work, double *__restrict__ carry,
-                                                     float *__restrict__ avgf, const int *__restrict__ list) {
-  extern __shared__ __attribute__((aligned(16))) float2 sm[]; // y (olen+1 entries, y[-1] first), then (ang, s0)
-  __shared__ double w_A[FMB_NT / 64], w_B[FMB_NT / 64];
-  __shared__ float red[FMB_NT / 64];
-  int const tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  int const ch = list[blockIdx.x], b = blockIdx.y;
-  const DemodDesc *dd = descs + ch;
-  const DemodState *st = states + ch;
-  const FmBlockStat *fs = fmstat + (size_t)ch * stat_stride;
-  int open, open_prev, so;
-  fm_squelch(fs, b, st->fm_squelch_open[par], open, open_prev, so); // uniform: every lane evaluates it
-  const float2 *y = baseband + (size_t)ch * bb_stride + (size_t)b * olen;
-  FmWork *wo = work + (size_t)ch * bb_stride + (size_t)b * olen;
-  int const flat = dd->flat;
-  float const gain = dd->fm_gain;
-  float const var = fs[b].variance;
-  // stage the block, preceded by `state` on entry (fm.c:86-87,123)
-  if (open) {
-    for (int n = tid; n < olen; n += FMB_NT) sm[n + 1] = y[n];
-    if (tid == 0) {
-      if (b == 0)
-        sm[0] = st->fm_state[par];
-      else
-        sm[0] = open_prev ? y[-1] : make_float2(0.f, 0.f);
-    }
-  }
-  __syncthreads();
-  // discriminator in place: sample n reads y_n (slot n+1) and y_{n-1} (slot n) and leaves (ang, weight) in
-  // slot n+1.  Batches of 256 samples run from the top down and read before anyone writes, so a slot is
-  // overwritten only after both of its readers are done.
-  float angsum = 0.f;
-  if (open) {
-    int const nbatch = (olen + FMB_NT - 1) / FMB_NT;
-#pragma unroll 1
-    for (int j = nbatch - 1; j >= 0; j--) {
-      int const n = tid + j * FMB_NT;
-      float ang = 0.f, amp = 0.f;
-      if (n < olen) {
-        float2 const p = cmulc(sm[n + 1], sm[n]);
-        ang = atan2f(p.y, p.x);        // cargf, fm.c:89
-        amp = hypotf(p.x, p.y) / var;  // cabsf(p) / fm_variance, fm.c:91
-        if (amp > 1) amp = 1;
-        angsum += ang;
-      }
-      __syncthreads();
-      if (n < olen) sm[n + 1] = make_float2(ang, amp);
-      __syncthreads();
-    }
-  }
-  // de-emphasis integrator from a zero carry-in: contiguous chunk per thread, affine maps scanned over the block
-  int const CH = (olen + FMB_NT - 1) / FMB_NT;
-  int const n0 = tid * CH;
-  int const n1 = (n0 + CH < olen) ? n0 + CH : olen;
-  double A = 1.0, B = 0.0; // this chunk's map carry_out = A*carry_in + B
-  if (!flat) {
-    if (open) {
-      for (int n = n0; n < n1; n++) {
-        float2 const aw = sm[n + 1];
-        double const x = (double)aw.x * .114 * (double)gain * (double)aw.y; // fm.c:110
-        B = (B + x) * FM_DECAY;
-        A *= FM_DECAY;
-      }
-    } else {
-      for (int n = n0; n < n1; n++) A *= FM_DECAY; // fm.c:130
-    }
-  }
-  double Ai = A, Bi = B;
-#pragma unroll
-  for (int o = 1; o < 64; o <<= 1) {
-    double const Ap = __shfl_up(Ai, o, 64), Bp = __shfl_up(Bi, o, 64);
-    if (lane >= o) {
-      Bi = Ai * Bp + Bi;
-      Ai = Ai * Ap;
-    }
-  }
-  if (lane == 63) {
-    w_A[wave] = Ai;
-    w_B[wave] = Bi;
-  }
-  __syncthreads();
-  double c = 0.0; // zero carry-in at the block start
-  for (int w = 0; w < wave; w++) c = w_A[w] * c + w_B[w];
-  double const Ae = __shfl_up(Ai, 1, 64), Be = __shfl_up(Bi, 1, 64);
-  double cin = lane == 0 ? c : Ae * c + Be; // carry into this thread's chunk
-  if (tid == FMB_NT - 1) carry[(size_t)ch * stat_stride + b] = Ai * c + Bi; // block's carry-out for carry-in 0
-  if (open) {
-    for (int n = n0; n < n1; n++) {
-      float2 const aw = sm[n + 1];
-      float s0;
-      if (flat) {
-        s0 = aw.x * gain; // fm.c:105
-      } else {
-        double const x = (double)aw.x * .114 * (double)gain * (double)aw.y;
-        cin += x;          // samples[n] = lastaudio += ...
-        s0 = (float)cin;
-        cin *= FM_DECAY;   // lastaudio *= 0.99376949
-      }
-      sm[n + 1] = make_float2(aw.x, s0);
-    }
-  }
-  __syncthreads();
-  for (int n = tid; n < olen; n += FMB_NT) {
-    float2 const v = open ? sm[n + 1] : make_float2(0.f, 0.f); // closed: audio is the decaying carry alone (fm.c:124-132)
-    wo[n] = FmWork{v.x, v.y};
-  }
-  float const tot = block_sum<FMB_NT>(angsum, red);
-  if (tid == 0) avgf[(size_t)ch * stat_stride + b] = tot / olen; // fm.c:96,114
+// sample 0 of block j (fm.c:86-93,110): p = y_j[0] * conj(state), state = last sample of block j-1 if that block was
+// demodulated, 0 if its squelch was closed (fm.c:123), the carried state for j == 0.  Returns the integrator
+// increment ang*.114*gain*amp; ang0 gets the angle.
+__device__ __forceinline__ double fm_sample0(const FmBlockStat *__restrict__ fs, int j, float2 state_in, int so_in,
+                                             float gain, float &ang0) {
+  float2 prev = state_in;
+  if (j > 0) prev = fm_is_open(fs, j - 1, so_in) ? fs[j - 1].last : make_float2(0.f, 0.f);
+  float2 const p = cmulc(fs[j].first, prev);
+  ang0 = atan2f(p.y, p.x);
+  float amp = hypotf(p.x, p.y) / fs[j].variance;
+  if (amp > 1) amp = 1;
+  return (double)ang0 * .114 * (double)gain * (double)amp;
 }
 
 // algorithmic bytes per (channel, block): 8*olen work read + 2*olen PCM written
-__global__ __launch_bounds__(FMB_NT) void kh_fm_finish(const float2 *__restrict__ baseband, size_t bb_stride, int olen,
-                                                       int nblocks, const DemodDesc *__restrict__ descs,
+__global__ __launch_bounds__(FMB_NT) void kh_fm_finish(int olen, int nblocks, const DemodDesc *__restrict__ descs,
                                                        DemodState *__restrict__ states, int par,
                                                        const FmBlockStat *__restrict__ fmstat, int stat_stride,
-                                                       const FmWork *__restrict__ work,
+                                                       const FmWork *__restrict__ work, size_t work_stride,
                                                        const double *__restrict__ carry,
-                                                       const float *__restrict__ avgf,
                                                        const double *__restrict__ decay_pow,
                                                        float *__restrict__ audio, int16_t *__restrict__ pcm,
                                                        size_t pcm_stride, int big_endian, kh_status *__restrict__ status,
                                                        int status_stride, const int *__restrict__ list) {
   extern __shared__ __attribute__((aligned(16))) float2 al[]; // (ang, lastaudio seen by the sample), olen entries
-  __shared__ double sh_c;
+  __shared__ double sh_c[2];
+  __shared__ float sh_ang0;
   __shared__ float red[FMB_NT / 64];
   int const tid = threadIdx.x;
   int const ch = list[blockIdx.x], b = blockIdx.y;
@@ -457,19 +344,29 @@ __global__ __launch_bounds__(FMB_NT) void kh_fm_finish(const float2 *__restrict_
   DemodState *st = states + ch;
   const FmBlockStat *fs = fmstat + (size_t)ch * stat_stride;
   int const flat = dd->flat;
-  float const dsamprate = dd->dsamprate;
-  int open, open_prev, so;
-  fm_squelch(fs, b, st->fm_squelch_open[par], open, open_prev, so);
+  float const dsamprate = dd->dsamprate, gain = dd->fm_gain;
+  int const so_in = st->fm_squelch_open[par];
+  float2 const state_in = st->fm_state[par];
+  int const open = fm_is_open(fs, b, so_in); // uniform: every lane evaluates it
+  int const so = fm_counter_after(fs, b, so_in);
   float const lastaudio_in = st->fm_lastaudio[par];
   if (tid < 64) {
-    // lastaudio on entry to this block: the carried value and the zero-carry outputs of the earlier blocks,
-    // each decayed over the blocks in between (fm.c:110-111,130): c = A^b c0 + sum_j A^(b-1-j) B_j
+    // lastaudio on entry to this block: the carried value and the carry-outs of the earlier open blocks, each
+    // decayed over the blocks in between (fm.c:110-111,130): c_b = A^b c_0 + sum_{j<b} A^(b-1-j) E_j with
+    // E_j = carry_j + A x0_j for a demodulated block (its own sample 0 enters ahead of the zero-carry run), 0 else
     double acc = 0.0;
     if (!flat) {
       double const Ablk = decay_pow[olen];
       const double *cb = carry + (size_t)ch * stat_stride;
       for (int j = tid - 1; j < b; j += 64) { // j = -1 stands for the carried lastaudio
-        double const v = j < 0 ? (double)lastaudio_in : cb[j];
+        double v;
+        if (j < 0)
+          v = (double)lastaudio_in;
+        else if (fm_is_open(fs, j, so_in)) {
+          float a0;
+          v = cb[j] + Ablk * fm_sample0(fs, j, state_in, so_in, gain, a0);
+        } else
+          v = 0.0;
         int m = b - 1 - j; // blocks to decay over
         double p = 1.0, q = Ablk;
         while (m) {
@@ -484,33 +381,45 @@ __global__ __launch_bounds__(FMB_NT) void kh_fm_finish(const float2 *__restrict_
     } else {
       acc = (double)lastaudio_in;
     }
-    if (tid == 0) sh_c = acc;
+    if (tid == 0) {
+      float a0 = 0.f;
+      double x0 = 0.0;
+      if (open) x0 = fm_sample0(fs, b, state_in, so_in, gain, a0);
+      sh_c[0] = acc;                     // lastaudio before sample 0
+      sh_c[1] = flat ? acc : acc + x0;   // and after its increment
+      sh_ang0 = a0;
+    }
   }
   __syncthreads();
-  double const c_in = sh_c;
-  const FmWork *wi = work + (size_t)ch * bb_stride + (size_t)b * olen;
+  double const c_in = sh_c[0], c0 = sh_c[1];
+  float const ang0 = sh_ang0;
+  const FmWork *wi = work + (size_t)ch * work_stride + (size_t)b * olen;
   size_t const obase = (size_t)b * olen;
   float *ao = audio ? audio + (size_t)ch * pcm_stride + obase : nullptr;
   int16_t *po = pcm + (size_t)ch * pcm_stride + obase;
   float lv = 0.f;
   for (int n = tid; n < olen; n += FMB_NT) {
-    FmWork const w = wi[n];
-    float s1, la;
-    if (flat) {
-      s1 = w.s0;
-      la = (float)c_in; // lastaudio never changes in flat mode
-    } else {
-      s1 = (float)((double)w.s0 + c_in * decay_pow[n]);
-      la = 0.f;
-      if (n > 0) { // lastaudio when sample n is processed = previous sample * decay (fm.c:110-111)
-        float const sp = (float)((double)wi[n - 1].s0 + c_in * decay_pow[n - 1]);
-        la = (float)((double)sp * FM_DECAY);
+    float s1, la = 0.f, ang = 0.f;
+    if (open) {
+      FmWork const w = wi[n];
+      ang = n ? w.ang : ang0;
+      if (flat) {
+        s1 = n ? w.s0 : ang0 * gain; // fm.c:105
+        la = (float)c_in;           // lastaudio never changes in flat mode
+      } else {
+        s1 = (float)((double)w.s0 + c0 * decay_pow[n]);
+        if (n > 0) { // lastaudio when sample n is processed = previous sample * decay (fm.c:110-111)
+          float const sp = (float)((double)wi[n - 1].s0 + c0 * decay_pow[n - 1]);
+          la = (float)((double)sp * FM_DECAY);
+        }
       }
+    } else {
+      s1 = flat ? 0.f : (float)(c_in * decay_pow[n]); // fm.c:124-132: the decaying carry alone
     }
     lv += s1 * s1;
     if (ao) ao[n] = s1;
     po[n] = pcm_word(s1, big_endian);
-    al[n] = make_float2(w.ang, la);
+    al[n] = make_float2(ang, la);
   }
   float const level = block_sum<FMB_NT>(lv, red) / olen; // fm.c:135-138 (its barriers also publish al[])
   if (tid >= 64) return;
@@ -560,7 +469,7 @@ __global__ __launch_bounds__(FMB_NT) void kh_fm_finish(const float2 *__restrict_
     r.foffset = NAN; // fm.c:116,121 leave both untouched while the squelch is closed
     r.pdeviation = NAN;
     if (open) {
-      float const avg_f = avgf[(size_t)ch * stat_stride + b];
+      float const avg_f = (fs[b].angsum + ang0) / olen; // fm.c:96,114
       r.foffset = (float)((double)(dsamprate * avg_f) * (0.5 * M_1_PI)); // fm.c:116
       pdev_pos -= avg_f;
       pdev_neg -= avg_f;
@@ -576,11 +485,11 @@ __global__ __launch_bounds__(FMB_NT) void kh_fm_finish(const float2 *__restrict_
     status[(size_t)ch * status_stride + b] = r;
     if (b == nblocks - 1) { // state carried to the next launch (fm.c:26,32,33)
       double c = c_in;
-      if (!flat) c = decay_pow[olen] * c + carry[(size_t)ch * stat_stride + b];
+      if (!flat) c = open ? decay_pow[olen] * c0 + carry[(size_t)ch * stat_stride + b] : decay_pow[olen] * c_in;
       // written to the other parity slot: workgroups of this launch may still be reading the current one
       st->fm_lastaudio[par ^ 1] = (float)c;
       st->fm_squelch_open[par ^ 1] = so;
-      st->fm_state[par ^ 1] = open ? baseband[(size_t)ch * bb_stride + obase + olen - 1] : make_float2(0.f, 0.f);
+      st->fm_state[par ^ 1] = open ? fs[b].last : make_float2(0.f, 0.f);
     }
   }
 }
@@ -820,13 +729,8 @@ int launch_demod(hipStream_t st, float2 *baseband, size_t bb_stride, int olen, i
       set_error("FM demodulator: olen %d outside [2, 8192]", olen);
       return -1;
     }
-    const FmBlockStat *fs = static_cast<const FmBlockStat *>(fm.stat);
-    FmWork *wk = static_cast<FmWork *>(fm.work);
-    hipLaunchKernelGGL(kh_fm_disc, dim3(n_fm, nblocks), dim3(FMB_NT), (olen + 1) * sizeof(float2), st, baseband, bb_stride, olen, desc, state, fm.parity,
-                       fs, status_stride, wk, fm.carry, fm.avgf, fm_list);
-    // kh_fm_finish reads the state kh_fm_disc read and then overwrites it: same stream, so ordered
-    hipLaunchKernelGGL(kh_fm_finish, dim3(n_fm, nblocks), dim3(FMB_NT), olen * sizeof(float2), st, baseband, bb_stride,
-                       olen, nblocks, desc, state, fm.parity, fs, status_stride, wk, fm.carry, fm.avgf, fm.decay_pow, audio, pcm,
+    hipLaunchKernelGGL(kh_fm_finish, dim3(n_fm, nblocks), dim3(FMB_NT), olen * sizeof(float2), st, olen, nblocks, desc,
+                       state, fm.parity, fm.stat, status_stride, fm.work, bb_stride, fm.carry, fm.decay_pow, audio, pcm,
                        pcm_stride, pcm_big_endian, stt, status_stride, fm_list);
   }
   if (n_lin > 0)

@@ -374,10 +374,10 @@ template <int ND, int NT>
 __global__ __launch_bounds__(NT) void kh_filter_out(const float2 *__restrict__ spec, size_t spec_in_stride, int N,
                                                     int in_real, const ChanDesc *__restrict__ chans,
                                                     const float2 *__restrict__ response, int olen, void *out,
-                                                    size_t out_stride, const float2 *__restrict__ tw,
-                                                    FmBlockStat *__restrict__ fm_stat, int stat_stride) {
+                                                    size_t out_stride, const float2 *__restrict__ tw, FmFront fm) {
   __shared__ __attribute__((aligned(16))) float2 f[ND];
   __shared__ float red[NT / 64 > 0 ? NT / 64 : 1];
+  __shared__ double w_A[NT / 64 > 0 ? NT / 64 : 1], w_B[NT / 64 > 0 ? NT / 64 : 1];
   int const tid = threadIdx.x;
   int const ch = blockIdx.x, b = blockIdx.y;
   ChanDesc const cd = chans[ch];
@@ -450,12 +450,16 @@ __global__ __launch_bounds__(NT) void kh_filter_out(const float2 *__restrict__ s
     float *o = static_cast<float *>(out) + (size_t)ch * out_stride + (size_t)b * olen;
     for (int n = tid; n < olen; n += NT) o[n] = f[ND - olen + n].x;
   } else {
-    float2 *o = static_cast<float2 *>(out) + (size_t)ch * out_stride + (size_t)b * olen;
-    for (int n = tid; n < olen; n += NT) o[n] = f[ND - olen + n];
-    if (fm_stat != nullptr && cd.fm_stats) { // fm.c:53-70 while the block is still in LDS
+    bool const is_fm = fm.stat != nullptr && cd.fm_stats; // uniform
+    if (!is_fm || fm.write_baseband) {
+      float2 *o = static_cast<float2 *>(out) + (size_t)ch * out_stride + (size_t)b * olen;
+      for (int n = tid; n < olen; n += NT) o[n] = f[ND - olen + n];
+    }
+    if (is_fm) { // fm.c:53-70 and the block-local part of fm.c:85-112 while the block is still in LDS
+      float2 *y = f + (ND - olen);
       float bb = 0.f, sa = 0.f;
       for (int n = tid; n < olen; n += NT) {
-        float2 const v = f[ND - olen + n];
+        float2 const v = y[n];
         float const t = v.x * v.x + v.y * v.y;
         bb += t;
         sa += sqrtf(t);
@@ -465,16 +469,20 @@ __global__ __launch_bounds__(NT) void kh_filter_out(const float2 *__restrict__ s
       float const avg = sa / olen;
       float var = 0.f;
       for (int n = tid; n < olen; n += NT) {
-        float2 const v = f[ND - olen + n];
+        float2 const v = y[n];
         float const a = sqrtf(v.x * v.x + v.y * v.y);
         var += (a - avg) * (a - avg);
       }
       var = block_sum<NT>(var, red) / (olen - 1);
-      if (tid < 64) { // wave 0 evaluates the Rice correction cooperatively (NT >= 64)
-        float snr = (float)fm_snr_wave((double)(avg * avg / var), tid);
-        if (tid == 0)
-          fm_stat[(size_t)ch * stat_stride + b] = FmBlockStat{bb / olen, var, fmaxf(0.0f, snr), 0.f};
-      }
+      float2 const first = y[0], last = y[olen - 1];
+      float snr = 0.f;
+      if (tid < 64) snr = (float)fm_snr_wave((double)(avg * avg / var), tid); // wave 0, cooperatively (NT >= 64)
+      __syncthreads(); // first/last are read before fm_front overwrites the block
+      const DemodDesc *dd = fm.descs + ch;
+      size_t const rec = (size_t)ch * fm.stat_stride + b;
+      float const angsum = fm_front<NT>(y, olen, dd->fm_gain, dd->flat, var, fm.work + (size_t)ch * fm.work_stride + (size_t)b * olen,
+                                        fm.carry + rec, red, w_A, w_B);
+      if (tid == 0) fm.stat[rec] = FmBlockStat{bb / olen, var, fmaxf(0.0f, snr), angsum, first, last};
     }
   }
 }
@@ -482,25 +490,25 @@ __global__ __launch_bounds__(NT) void kh_filter_out(const float2 *__restrict__ s
 template <int ND>
 static int launch_fo(hipStream_t st, const float2 *spec, size_t spec_in_stride, int N, int in_real, const ChanDesc *chans,
                      const float2 *response, int olen, void *out, size_t out_stride, int nblocks, int nchan,
-                     void *fm_stat, int stat_stride) {
+                     FmFront const &fm) {
   constexpr int NT = (ND / 4 < 256) ? ND / 4 : 256;
   const float2 *tw = twiddle_table(ND);
   if (!tw) return -1;
   hipLaunchKernelGGL((kh_filter_out<ND, NT>), dim3(nchan, nblocks), dim3(NT), 0, st, spec, spec_in_stride, N, in_real,
-                     chans, response, olen, out, out_stride, tw, static_cast<FmBlockStat *>(fm_stat), stat_stride);
+                     chans, response, olen, out, out_stride, tw, fm);
   return KH_HIP(hipGetLastError()) ? 0 : -1;
 }
 
 int launch_filter_output(hipStream_t st, const float2 *spec, size_t spec_in_stride, int N, int in_real,
                          const ChanDesc *chans, const float2 *response, int ND, int olen, void *out, size_t out_stride,
-                         int nblocks, int nchan, void *fm_stat, int stat_stride) {
+                         int nblocks, int nchan, FmFront const &fm) {
   if (nblocks <= 0 || nchan <= 0) return 0;
   if (olen > ND || ND > N) {
     set_error("filter output: olen %d > N_dec %d or N_dec > N %d", olen, ND, N);
     return -1;
   }
 #define FO(n) \
-  case n: return launch_fo<n>(st, spec, spec_in_stride, N, in_real, chans, response, olen, out, out_stride, nblocks, nchan, fm_stat, stat_stride)
+  case n: return launch_fo<n>(st, spec, spec_in_stride, N, in_real, chans, response, olen, out, out_stride, nblocks, nchan, fm)
   switch (ND) {
     FO(256);
     FO(512);

@@ -2,6 +2,7 @@
 // and the FM kernels.
 #pragma once
 #include <hip/hip_runtime.h>
+#include "kh_internal.h"
 
 namespace kh {
 static __device__ double fm_i0(double z) { // fm.c:152-163
@@ -107,9 +108,89 @@ __device__ __forceinline__ float block_sum(float v, float *red) {
   return t;
 }
 
-// per (FM channel, block) record left by the filter-output epilogue (fm.c:53-70)
-struct FmBlockStat {
-  float bb_power, variance, snr, pad;
-};
+constexpr double FM_DECAY = 0.99376949; // fm.c:111,130
+
+// fm.c:86-111 for one block that sits in LDS, for everything that does not depend on the neighbouring blocks:
+// the conjugate-product discriminator and threshold-extension weight of samples 1 .. olen-1 (sample 0 needs the
+// last sample of the block before and the squelch history: kh_fm_finish supplies it as part of the carry), and the
+// de-emphasis integrator run from a ZERO carry-in.  y[0 .. olen) is overwritten.  Leaves (ang, s0) per sample in
+// `wo`, the block's carry-out for carry-in zero in *carry_out, and returns the sum of the angles (every thread).
+// The squelch decision is not known here: the result is simply not used by kh_fm_finish for a closed block.
+template <int NT>
+__device__ __forceinline__ float fm_front(float2 *y, int olen, float gain, int flat, float var, FmWork *__restrict__ wo,
+                                          double *__restrict__ carry_out, float *red, double *w_A, double *w_B) {
+  int const tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  // discriminator in place: sample n reads y[n] and y[n-1] and leaves (ang, weight) in y[n].  Batches of NT samples
+  // run from the top down and read before anyone writes, so a slot is overwritten only after both readers are done.
+  float angsum = 0.f;
+  int const nbatch = (olen + NT - 1) / NT;
+#pragma unroll 1
+  for (int j = nbatch - 1; j >= 0; j--) {
+    int const n = tid + j * NT;
+    float ang = 0.f, amp = 0.f;
+    if (n >= 1 && n < olen) {
+      float2 const a = y[n], b = y[n - 1];
+      float2 const p = make_float2(a.x * b.x + a.y * b.y, a.y * b.x - a.x * b.y); // y[n] * conj(y[n-1])
+      ang = atan2f(p.y, p.x);       // cargf, fm.c:89
+      amp = hypotf(p.x, p.y) / var; // cabsf(p) / fm_variance, fm.c:91
+      if (amp > 1) amp = 1;
+      angsum += ang;
+    }
+    __syncthreads();
+    if (n < olen) y[n] = make_float2(ang, amp);
+    __syncthreads();
+  }
+  // de-emphasis integrator from a zero carry-in: contiguous chunk per thread, affine maps scanned over the block
+  int const CH = (olen + NT - 1) / NT;
+  int const n0 = tid * CH < olen ? tid * CH : olen;
+  int const n1 = (n0 + CH < olen) ? n0 + CH : olen;
+  double A = 1.0, B = 0.0; // this chunk's map carry_out = A*carry_in + B
+  if (!flat) {
+    for (int n = n0; n < n1; n++) {
+      float2 const aw = y[n];
+      double const x = (double)aw.x * .114 * (double)gain * (double)aw.y; // fm.c:110
+      B = (B + x) * FM_DECAY;
+      A *= FM_DECAY;
+    }
+  }
+  double Ai = A, Bi = B;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    double const Ap = __shfl_up(Ai, o, 64), Bp = __shfl_up(Bi, o, 64);
+    if (lane >= o) {
+      Bi = Ai * Bp + Bi;
+      Ai = Ai * Ap;
+    }
+  }
+  if (lane == 63) {
+    w_A[wave] = Ai;
+    w_B[wave] = Bi;
+  }
+  __syncthreads();
+  double c = 0.0; // zero carry-in at the block start
+  for (int w = 0; w < wave; w++) c = w_A[w] * c + w_B[w];
+  double const Ae = __shfl_up(Ai, 1, 64), Be = __shfl_up(Bi, 1, 64);
+  double cin = lane == 0 ? c : Ae * c + Be; // carry into this thread's chunk
+  if (tid == NT - 1) *carry_out = Ai * c + Bi;
+  for (int n = n0; n < n1; n++) {
+    float2 const aw = y[n];
+    float s0;
+    if (flat) {
+      s0 = aw.x * gain; // fm.c:105
+    } else {
+      double const x = (double)aw.x * .114 * (double)gain * (double)aw.y;
+      cin += x;        // samples[n] = lastaudio += ...
+      s0 = (float)cin;
+      cin *= FM_DECAY; // lastaudio *= 0.99376949
+    }
+    y[n] = make_float2(aw.x, s0);
+  }
+  __syncthreads();
+  for (int n = tid; n < olen; n += NT) {
+    float2 const v = y[n];
+    wo[n] = FmWork{v.x, v.y};
+  }
+  return block_sum<NT>(angsum, red);
+}
 
 } // namespace kh

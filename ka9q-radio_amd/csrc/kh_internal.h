@@ -33,11 +33,30 @@ struct ChanDesc {     // one per channel, read by the filter-output kernel
   int fm_stats;       // 1: the epilogue leaves fm.c:53-70's block statistics for the FM kernels
 };
 
-struct FmScratch {    // device scratch of the FM path (see kh_demod_kernels.hip)
-  void *stat;         // FmBlockStat[nchan][status_stride], written by kh_filter_out
-  void *work;         // FmWork[nchan][bb_stride]
-  double *carry;      // [nchan][status_stride]
-  float *avgf;        // [nchan][status_stride]
+// FM path scratch.  The filter-output epilogue (kh_filter_out) leaves, per FM channel and block, the block
+// statistics and the block-local part of the demodulator; kh_fm_finish folds in what depends on earlier blocks.
+struct FmBlockStat {
+  float bb_power, variance, snr; // fm.c:53-70
+  float angsum;                  // sum of the discriminator angles of samples 1 .. olen-1 (fm.c:96)
+  float2 first, last;            // y[0], y[olen-1]: sample 0's angle needs the block before (fm.c:86-87)
+};
+struct FmWork { // per sample: discriminator angle and the de-emphasis integrator run from a zero carry-in
+  float ang, s0;
+};
+struct DemodDesc;
+struct FmFront {      // handed to launch_filter_output; stat == nullptr: no FM channels
+  FmBlockStat *stat;  // [nchan][stat_stride]
+  FmWork *work;       // [nchan][work_stride]
+  double *carry;      // [nchan][stat_stride]: carry-out of the integrator for carry-in zero
+  const DemodDesc *descs;
+  int stat_stride;
+  size_t work_stride;
+  int write_baseband; // 0: FM channels do not store their complex baseband
+};
+struct FmScratch {    // handed to launch_demod
+  FmBlockStat *stat;
+  FmWork *work;
+  double *carry;
   const double *decay_pow; // 0.99376949^k, k <= olen
   int parity;         // which DemodState FM slot this launch reads
 };
@@ -103,8 +122,7 @@ int launch_forward_fft(hipStream_t st, const void *time, size_t in_stride, int r
 // out + ch*out_stride + b*olen.
 int launch_filter_output(hipStream_t st, const float2 *spec, size_t spec_in_stride, int N, int in_real,
                          const ChanDesc *chans, const float2 *response, int ND, int olen, void *out, size_t out_stride,
-                         int nblocks, int nchan, void *fm_stat /*FmBlockStat[nchan][stat_stride] or null*/,
-                         int stat_stride);
+                         int nblocks, int nchan, FmFront const &fm);
 // wire format -> cf32 * gain * Doppler * LO2 and per-block energy (radio.c:136-191)
 // energy_part: ingest_chunks(L) floats per (input, block), summed by launch_n0
 int ingest_chunks(int L);

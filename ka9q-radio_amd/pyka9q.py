@@ -27,7 +27,7 @@ EXPORTS = [
     "kh_bank_write_zeros", "kh_bank_set_gain", "kh_bank_raw_device_ptr", "kh_bank_commit_input",
     "kh_bank_execute", "kh_bank_sync", "kh_bank_read_baseband", "kh_bank_read_pcm", "kh_bank_read_audio",
     "kh_bank_read_status", "kh_bank_read_input_status", "kh_bank_read_spectrum", "kh_bank_read_response",
-    "kh_bank_pcm_device_ptr", "kh_bank_keep_audio", "kh_bank_stream", "kh_bank_profile", "kh_bank_stage_times",
+    "kh_bank_pcm_device_ptr", "kh_bank_keep_audio", "kh_bank_keep_baseband", "kh_bank_use_graph", "kh_bank_stream", "kh_bank_profile", "kh_bank_stage_times",
     "kh_stage_kernel_name",
 ]
 
@@ -148,6 +148,8 @@ def lib():
     L.kh_bank_stream.argtypes = [C.c_void_p]
     L.kh_bank_profile.argtypes = [C.c_void_p, C.c_int]
     L.kh_bank_keep_audio.argtypes = [C.c_void_p, C.c_int]
+    L.kh_bank_keep_baseband.argtypes = [C.c_void_p, C.c_int]
+    L.kh_bank_use_graph.argtypes = [C.c_void_p, C.c_int]
     L.kh_bank_stage_times.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_uint)]
     L.kh_stage_kernel_name.restype = C.c_char_p
     L.kh_stage_kernel_name.argtypes = [C.c_int]
@@ -352,6 +354,12 @@ class Bank:
 
     def keep_audio(self, enable):
         _check(self.lib.kh_bank_keep_audio(self.h, int(enable)), "kh_bank_keep_audio")
+
+    def use_graph(self, enable):
+        _check(self.lib.kh_bank_use_graph(self.h, int(enable)), "kh_bank_use_graph")
+
+    def keep_baseband(self, enable):
+        _check(self.lib.kh_bank_keep_baseband(self.h, int(enable)), "kh_bank_keep_baseband")
 
     def write_input_device(self, inp, dptr, count):
         _check(self.lib.kh_bank_write_input(self.h, inp, dptr, count), "kh_bank_write_input")

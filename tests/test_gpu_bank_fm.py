@@ -95,3 +95,57 @@ def test_fm_bank_192k_flat_and_deemph(hip):
         # +-8 kHz filter of the reference's FM preset (main.c:132-146) would need other edges; the helper
         # uses +-5.5 kHz, still wide enough for 3 kHz deviation + 1 kHz tone by Carson's rule.
         _run_pair(hip, L, M, D, fs, bank_chans, x.astype(np.complex64), T, calls, flat=flat)
+
+
+def test_fm_squelch_transitions_and_no_baseband_mode(hip):
+    """A carrier keyed on and off block by block: the squelch opens, holds its one-block tail and closes (fm.c:73-78),
+    `state` is zeroed while closed (fm.c:123), so sample 0 of a block is demodulated against the last sample of the
+    block before, against zero, or against the state carried from the launch before.  Every variant must match the
+    oracle, in both de-emphasis modes; and with kh_bank_keep_baseband(0) the PCM and status must not change by a bit."""
+    fs, L, M, D = 192_000, 3840, 4353, 4
+    olen = L // D
+    T, calls = 6, 3
+    n = T * calls * L
+    keyed = np.array([1, 1, 0, 0, 0, 1, 0, 1, 1, 1, 0, 0, 1, 0, 0, 0, 1, 1], np.float32)  # per block
+    env = np.repeat(keyed, L)
+    x = (synth.noise(n, 0.01, 5) + env * synth.fm_carrier(0, n, fs, 0.0, 0.4, 700.0, 2500.0)).astype(np.complex64)
+    for flat in (0, 1):
+        kw = dict(rotate=0, low=-5500.0, high=5500.0, kaiser_beta=3.0, flat=flat)
+        bank = hip.Bank(L, M, D, 1, 1, T, fs)
+        lean = hip.Bank(L, M, D, 1, 1, T, fs)
+        lean.keep_baseband(0)
+        pipe = pipeline.Pipeline(L, M, D, fs)
+        bank.set_channel(0, demod=hip.KH_DEMOD_FM, **kw)
+        lean.set_channel(0, demod=hip.KH_DEMOD_FM, **kw)
+        pipe.add_channel(demod="fm", **kw)
+        seen = set()
+        for call in range(calls):
+            seg = x[call * T * L:(call + 1) * T * L]
+            for bk in (bank, lean):
+                bk.write_input(0, seg)
+                bk.execute(T)
+            pcm, st = bank.pcm(0, T), bank.status(0, T)
+            assert np.array_equal(pcm, lean.pcm(0, T)) and st.tobytes() == lean.status(0, T).tobytes()
+            for b in range(T):
+                outs, _ = pipe.run_block([seg[b * L:(b + 1) * L]])
+                _y, audio, sig = outs[0]
+                sl = slice(b * olen, (b + 1) * olen)
+                d = np.abs(pcm[sl].astype(np.int32) - orc_scaleclip(audio).astype(np.int32))
+                if flat:
+                    # without the amplitude weight of fm.c:91-93 the angle of a near-zero sample pair is ill-conditioned
+                    # (a 1e-7 baseband difference moves arg() of a 1e-4 sample by 1e-3 rad): the +-1 LSB bar is applied
+                    # where both samples carry at least 2 % of the block's RMS amplitude, 16 LSB elsewhere
+                    a = np.abs(_y)
+                    ok = np.minimum(a, np.concatenate(([a[0]], a[:-1]))) > 0.02 * np.sqrt(np.mean(a * a))
+                    assert d[ok].max() <= 1 and d.max() <= 16, (flat, call, b, int(d[ok].max()), int(d.max()))
+                else:
+                    assert d.max() <= 1, (flat, call, b, int(d.max()))
+                so = int(pipe.channels[0].dem.st.squelch_open)  # the oracle's counter after this block
+                assert int(st[b]["squelch_open"]) == so, (flat, call, b)
+                seen.add(so)
+                if sig["snr"] > 4:
+                    for key in ("foffset", "pdeviation"):
+                        assert abs(st[b][key] - sig[key]) <= 1e-4 * abs(sig[key]) + 2e-3, (key, flat, call, b)
+        assert seen == {0, 1}
+        bank.close()
+        lean.close()
