@@ -58,13 +58,20 @@ struct kh_bank {
   hipStream_t stream = nullptr;
   hipStream_t side = nullptr;             // compute_n0's second iteration runs here, beside the channel kernels
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+  // The launch is cut in two: FRONT (convert + mix, forward FFT: streams the whole block through HBM) on `front`,
+  // BACK (compute_n0, channels, demodulators: little memory traffic, latency bound) on `stream`.  Everything the
+  // front hands to the back is double buffered (sp = slot of the current launch), so the front of launch k+1 runs
+  // beside the back of launch k.
+  hipStream_t front = nullptr;
+  hipEvent_t ev_front_done[2] = {}, ev_back_done[2] = {};
+  int sp = 0, last_sp = 0, pipeline = 1;
   // device
   unsigned char *d_raw = nullptr;
   size_t raw_stride = 0; // bytes per input
   float2 *d_time[2] = {nullptr, nullptr};
   size_t time_stride = 0; // samples per input: (M-1) + T*L (+pad)
   int cur = 0;
-  float2 *d_spec = nullptr, *d_tmp = nullptr;
+  float2 *d_spec[2] = {}, *d_tmp = nullptr;
   size_t spec_stride = 0; // T*N
   ChanDesc *d_chans = nullptr;
   float2 *d_resp = nullptr;
@@ -82,7 +89,7 @@ struct kh_bank {
   size_t pcm_stride = 0; // 2*T*olen
   kh_status *d_status = nullptr;
   kh_input_status *d_istatus = nullptr;
-  float *d_energy = nullptr, *d_n0acc = nullptr, *d_n0state = nullptr, *d_scalar = nullptr;
+  float *d_energy[2] = {}, *d_n0acc[2] = {}, *d_n0state = nullptr, *d_scalar = nullptr;
   int *d_lists = nullptr; // fm | linear | am, C entries each
   FmBlockStat *d_fmstat = nullptr; // FM path scratch (kh_internal.h)
   FmWork *d_fmwork = nullptr;
@@ -104,9 +111,10 @@ struct kh_bank {
   // hipGraph cache: the kernel sequence of one execute call, captured the second time a shape is seen
   struct GraphEntry {
     unsigned nblocks;
-    int cur, fmpar;
+    int cur, fmpar, sp;
+    bool pipelined;
     int seen;              // launches seen with this key; -1: capture failed, stay eager
-    hipGraphExec_t exec;
+    hipGraphExec_t front, back;
   };
   std::vector<GraphEntry> graphs;
   int use_graph = 1, use_side = 1;
@@ -120,8 +128,10 @@ struct kh_bank {
 static bool is_pow2(unsigned v) { return v && !(v & (v - 1)); }
 
 static void drop_graphs(kh_bank *b) { // anything a captured launch baked in has changed
-  for (auto &g : b->graphs)
-    if (g.exec) hipGraphExecDestroy(g.exec);
+  for (auto &g : b->graphs) {
+    if (g.front) hipGraphExecDestroy(g.front);
+    if (g.back) hipGraphExecDestroy(g.back);
+  }
   b->graphs.clear();
 }
 
@@ -131,10 +141,12 @@ int kh_bank_destroy(kh_bank *b) {
   if (!b) return 0;
   if (b->stream) hipStreamSynchronize(b->stream);
   if (b->side) hipStreamSynchronize(b->side);
+  if (b->front) hipStreamSynchronize(b->front);
   drop_graphs(b);
-  void *ptrs[] = {b->d_raw,   b->d_time[0], b->d_time[1], b->d_spec,   b->d_tmp,    b->d_chans,  b->d_resp,
+  void *ptrs[] = {b->d_raw,   b->d_time[0], b->d_time[1], b->d_spec[0], b->d_spec[1], b->d_tmp, b->d_chans, b->d_resp,
                   b->d_ddesc, b->d_dstate,  b->d_idesc,   b->d_bb,     b->d_audio,  b->d_pcm,    b->d_status,
-                  b->d_istatus, b->d_energy, b->d_n0acc,  b->d_n0state, b->d_scalar, b->d_lists,
+                  b->d_istatus, b->d_energy[0], b->d_energy[1], b->d_n0acc[0], b->d_n0acc[1], b->d_n0state, b->d_scalar,
+                  b->d_lists,
                   b->d_fmstat, b->d_fmwork, b->d_fmcarry, b->d_decaypow};
   for (void *p : ptrs)
     if (p) hipFree(p);
@@ -145,7 +157,12 @@ int kh_bank_destroy(kh_bank *b) {
   if (b->h_idesc) hipHostFree(b->h_idesc);
   if (b->ev_fork) hipEventDestroy(b->ev_fork);
   if (b->ev_join) hipEventDestroy(b->ev_join);
+  for (auto &e : b->ev_front_done)
+    if (e) hipEventDestroy(e);
+  for (auto &e : b->ev_back_done)
+    if (e) hipEventDestroy(e);
   if (b->side) hipStreamDestroy(b->side);
+  if (b->front) hipStreamDestroy(b->front);
   if (b->stream) hipStreamDestroy(b->stream);
   delete b;
   return 0;
@@ -191,6 +208,9 @@ kh_bank *kh_bank_create(const struct kh_bank_config *cfg) {
   size_t const T = b->T, C = b->C, P = b->P, L = cfg->L, M = cfg->M;
   bool ok = KH_HIP(hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking));
   ok = ok && KH_HIP(hipStreamCreateWithFlags(&b->side, hipStreamNonBlocking));
+  ok = ok && KH_HIP(hipStreamCreateWithFlags(&b->front, hipStreamNonBlocking));
+  for (auto &e : b->ev_front_done) ok = ok && KH_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+  for (auto &e : b->ev_back_done) ok = ok && KH_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
   ok = ok && KH_HIP(hipHostMalloc((void **)&b->h_idesc, kh_bank::IDESC_SLOTS * P * sizeof(IngestDesc), hipHostMallocDefault));
   for (auto &e : b->idesc_ev) ok = ok && KH_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
   ok = ok && KH_HIP(hipEventCreateWithFlags(&b->ev_fork, hipEventDisableTiming));
@@ -208,7 +228,8 @@ kh_bank *kh_bank_create(const struct kh_bank_config *cfg) {
   A(&b->d_raw, P * b->raw_stride, true);
   A(&b->d_time[0], P * b->time_stride * sizeof(float2), true);
   A(&b->d_time[1], P * b->time_stride * sizeof(float2), true);
-  A(&b->d_spec, P * b->spec_stride * sizeof(float2), false);
+  A(&b->d_spec[0], P * b->spec_stride * sizeof(float2), false);
+  A(&b->d_spec[1], P * b->spec_stride * sizeof(float2), false);
   if (N > KH_MAX_SMALL_N) A(&b->d_tmp, P * b->spec_stride * sizeof(float2), false);
   A(&b->d_chans, C * sizeof(ChanDesc), true);
   A(&b->d_resp, C * ND * sizeof(float2), true);
@@ -220,8 +241,10 @@ kh_bank *kh_bank_create(const struct kh_bank_config *cfg) {
   A(&b->d_pcm, C * b->pcm_stride * sizeof(int16_t), true);
   A(&b->d_status, C * T * sizeof(kh_status), true);
   A(&b->d_istatus, P * T * sizeof(kh_input_status), true);
-  A(&b->d_energy, P * T * ingest_chunks(cfg->L) * sizeof(float), true);
-  A(&b->d_n0acc, n0_part_floats() * P * T * sizeof(float), true);
+  for (int k = 0; k < 2; k++) {
+    A(&b->d_energy[k], P * T * ingest_chunks(cfg->L) * sizeof(float), true);
+    A(&b->d_n0acc[k], n0_part_floats() * P * T * sizeof(float), true);
+  }
   A(&b->d_n0state, P * sizeof(float), false);
   A(&b->d_scalar, sizeof(float), true);
   A(&b->d_lists, 3 * C * sizeof(int), true);
@@ -250,6 +273,7 @@ kh_bank *kh_bank_create(const struct kh_bank_config *cfg) {
   }
   if (const char *e = getenv("KA9Q_HIP_GRAPH")) b->use_graph = atoi(e);
   if (const char *e = getenv("KA9Q_HIP_SIDE")) b->use_side = atoi(e);
+  if (const char *e = getenv("KA9Q_HIP_PIPELINE")) b->pipeline = atoi(e);
   b->chans.assign(C, ChanDesc{0, 0, COMPLEX, 0});
   b->ddesc.assign(C, DemodDesc{});
   b->ccfg.assign(C, kh_channel_config{});
@@ -387,9 +411,10 @@ int kh_bank_write_input(kh_bank *b, unsigned int input, const void *payload, siz
     return -1;
   }
   unsigned char *dst = b->d_raw + input * b->raw_stride + payload_bytes(b->cfg.payload, b->fill[input]);
-  if (!KH_HIP(hipMemcpyAsync(dst, payload, payload_bytes(b->cfg.payload, count), hipMemcpyDefault, b->stream)))
+  // on the front stream: behind the ingest of any launch still reading the ring
+  if (!KH_HIP(hipMemcpyAsync(dst, payload, payload_bytes(b->cfg.payload, count), hipMemcpyDefault, b->front)))
     return -1;
-  if (!KH_HIP(hipStreamSynchronize(b->stream))) return -1; // the caller may reuse its buffer
+  if (!KH_HIP(hipStreamSynchronize(b->front))) return -1; // the caller may reuse its buffer
   b->fill[input] += count;
   return 0;
 }
@@ -401,7 +426,7 @@ int kh_bank_write_zeros(kh_bank *b, unsigned int input, size_t count) {
     return -1;
   }
   unsigned char *dst = b->d_raw + input * b->raw_stride + payload_bytes(b->cfg.payload, b->fill[input]);
-  if (!KH_HIP(hipMemsetAsync(dst, 0, payload_bytes(b->cfg.payload, count), b->stream))) return -1;
+  if (!KH_HIP(hipMemsetAsync(dst, 0, payload_bytes(b->cfg.payload, count), b->front))) return -1;
   b->fill[input] += count;
   return 0;
 }
@@ -438,63 +463,85 @@ static int upload_channels(kh_bank *b) {
   return ok ? 0 : -1;
 }
 
-// the kernel sequence of one execute call: everything between the oscillator snapshot and the ring bookkeeping.
-// Runs eagerly, or under stream capture when kh_bank_execute builds the hipGraph of this shape.
-static int enqueue(kh_bank *b, unsigned int nblocks, bool prof) {
-  int const L = b->cfg.L, M = b->cfg.M, N = b->N, P = b->P, C = b->C;
+// The kernel sequence of one execute call, in two halves.  Both run eagerly, or under stream capture when
+// kh_bank_execute builds the hipGraphs of this shape.
+// FRONT: convert + mix (radio.c:136-191) and the forward transform (filter.c:212-238) into slot b->sp.
+static int enqueue_front(kh_bank *b, hipStream_t st, unsigned int nblocks, bool prof) {
+  int const L = b->cfg.L, M = b->cfg.M, N = b->N, P = b->P, sp = b->sp;
   size_t const need = (size_t)nblocks * L;
-  hipStream_t st = b->stream;
-  int e = 0;
-  auto mark = [&]() {
-    if (prof) hipEventRecord(b->ev[e], st);
-    e++;
-  };
   float2 *time = b->d_time[b->cur];
-  mark(); // 0
+  if (prof) hipEventRecord(b->ev[0], st);
   // the last M-1 samples of the launch are the next launch's overlap-save history (filter.c:230): ingest stores
   // them at the head of the other buffer as it goes, unless the history reaches back beyond this launch
   bool const fused_carry = (size_t)(M - 1) <= need;
-  if (launch_ingest(st, b->d_raw, b->raw_stride, b->cfg.payload, time + (M - 1), b->time_stride, b->d_idesc, b->d_energy,
-                    L, nblocks, P, fused_carry ? b->d_time[b->cur ^ 1] : nullptr, need - (fused_carry ? (M - 1) : 0)))
+  if (launch_ingest(st, b->d_raw, b->raw_stride, b->cfg.payload, time + (M - 1), b->time_stride, b->d_idesc,
+                    b->d_energy[sp], L, nblocks, P, fused_carry ? b->d_time[b->cur ^ 1] : nullptr,
+                    need - (fused_carry ? (M - 1) : 0)))
     return -1;
-  mark(); // 1
+  if (prof) hipEventRecord(b->ev[1], st);
   // launch_forward_fft records the mid event (ev[2]) between the two passes itself
   N0Plan const plan = n0_plan(N, b->cfg.samprate, b->cfg.n0_low, b->cfg.n0_high);
   bool const n0_on = b->cfg.compute_n0 && plan.valid;
-  if (launch_forward_fft(st, time, b->time_stride, 0, b->d_spec, b->d_tmp, b->spec_stride, N, L, nblocks, P,
-                         prof ? b->ev[2] : nullptr, N0Fuse{n0_on ? b->d_n0acc : nullptr, plan.start, plan.bincount}))
+  if (launch_forward_fft(st, time, b->time_stride, 0, b->d_spec[sp], b->d_tmp, b->spec_stride, N, L, nblocks, P,
+                         prof ? b->ev[2] : nullptr, N0Fuse{n0_on ? b->d_n0acc[sp] : nullptr, plan.start, plan.bincount}))
     return -1;
-  e = 3;
-  mark(); // 3
+  // overlap-save history for the next call (filter.c:230), into the other buffer
+  if (!fused_carry && launch_carry(st, time + need, b->d_time[b->cur ^ 1], b->time_stride * sizeof(float2),
+                                   (size_t)(M - 1) * sizeof(float2), P))
+    return -1;
+  if (prof) hipEventRecord(b->ev[3], st);
+  return 0;
+}
+// BACK: compute_n0 (radio.c:422-465), per channel filter output (filter.c:240-384), demodulators, scaleclip.
+static int enqueue_back(kh_bank *b, hipStream_t st, unsigned int nblocks, bool prof) {
+  int const L = b->cfg.L, N = b->N, P = b->P, C = b->C, sp = b->sp;
+  N0Plan const plan = n0_plan(N, b->cfg.samprate, b->cfg.n0_low, b->cfg.n0_high);
   // compute_n0's second iteration and the smoothing only read the spectrum: they run on the side stream while the
   // channel kernels run on this one (joined below).  With per-stage timing on, everything stays on one stream.
   bool const fork = !prof && b->use_side;
   hipStream_t const sn = fork ? b->side : st;
   if (fork && (!KH_HIP(hipEventRecord(b->ev_fork, st)) || !KH_HIP(hipStreamWaitEvent(sn, b->ev_fork, 0)))) return -1;
-  if (launch_n0(sn, b->cfg.compute_n0 ? b->d_spec : nullptr, b->spec_stride, N, b->cfg.samprate, plan, b->d_energy, L,
-                b->d_n0state, b->d_n0acc, b->d_istatus, nblocks, P))
+  if (launch_n0(sn, b->cfg.compute_n0 ? b->d_spec[sp] : nullptr, b->spec_stride, N, b->cfg.samprate, plan, b->d_energy[sp],
+                L, b->d_n0state, b->d_n0acc[sp], b->d_istatus, nblocks, P))
     return -1;
   if (fork && !KH_HIP(hipEventRecord(b->ev_join, sn))) return -1;
-  mark(); // 4
-  if (launch_filter_output(st, b->d_spec, b->spec_stride, N, 0, b->d_chans, b->d_resp, b->ND, b->olen, b->d_bb,
+  if (prof) hipEventRecord(b->ev[4], st);
+  if (launch_filter_output(st, b->d_spec[sp], b->spec_stride, N, 0, b->d_chans, b->d_resp, b->ND, b->olen, b->d_bb,
                            b->bb_stride, nblocks, C,
                            FmFront{b->n_fm ? b->d_fmstat : nullptr, b->d_fmwork, b->d_fmcarry, b->d_ddesc, b->T, b->bb_stride,
-                                   b->keep_baseband}))
+                                   b->keep_baseband},
+                           1))
     return -1;
-  mark(); // 5
+  if (prof) hipEventRecord(b->ev[5], st);
   if (launch_demod(st, b->d_bb, b->bb_stride, b->olen, nblocks, C, b->d_ddesc, b->d_dstate,
                    b->keep_audio ? b->d_audio : nullptr, b->d_pcm, b->pcm_stride, b->cfg.pcm_big_endian, b->d_status,
                    b->T, b->d_lists, b->n_fm, b->d_lists + C, b->n_lin, b->d_lists + 2 * C, b->n_am,
                    FmScratch{b->d_fmstat, b->d_fmwork, b->d_fmcarry, b->d_decaypow, b->fm_parity}))
     return -1;
-  mark(); // 6
-  // overlap-save history for the next call (filter.c:230), into the other buffer
-  if (!fused_carry && launch_carry(st, time + need, b->d_time[b->cur ^ 1], b->time_stride * sizeof(float2),
-                                   (size_t)(M - 1) * sizeof(float2), P))
-    return -1;
-  mark(); // 7
+  if (prof) hipEventRecord(b->ev[6], st);
   if (fork && !KH_HIP(hipStreamWaitEvent(st, b->ev_join, 0))) return -1;
   return 0;
+}
+
+// run one half eagerly, or capture it into a hipGraph the second time its shape is seen and replay it from then on
+static int run_half(kh_bank *b, hipStream_t st, unsigned int nblocks, int (*half)(kh_bank *, hipStream_t, unsigned int, bool),
+                    hipGraphExec_t *exec, int seen) {
+  if (!b->use_graph || seen < 1) return half(b, st, nblocks, false);
+  if (!*exec) {
+    hipGraph_t graph = nullptr;
+    bool ok = KH_HIP(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
+    if (ok) {
+      int const erc = half(b, st, nblocks, false);
+      ok = KH_HIP(hipStreamEndCapture(st, &graph)) && erc == 0 && graph != nullptr;
+    }
+    if (ok) ok = KH_HIP(hipGraphInstantiate(exec, graph, nullptr, nullptr, 0));
+    if (graph) hipGraphDestroy(graph);
+    if (!ok) {
+      *exec = nullptr;
+      return -2; // capture failed: the caller falls back to eager launches for this shape
+    }
+  }
+  return KH_HIP(hipGraphLaunch(*exec, st)) ? 0 : -1;
 }
 
 int kh_bank_execute(kh_bank *b, unsigned int nblocks) {
@@ -512,7 +559,10 @@ int kh_bank_execute(kh_bank *b, unsigned int nblocks) {
       return -1;
     }
   if (b->chans_dirty && upload_channels(b)) return -1;
-  hipStream_t st = b->stream;
+  bool const prof = b->profiling;
+  hipStream_t const sb = b->stream;                                // back half
+  hipStream_t const sf = (prof || !b->pipeline) ? sb : b->front;   // front half
+  int const sp = b->sp;
   // oscillator snapshot for this launch, staged through a pinned ring so that the host never waits for the device
   int const slot = b->idesc_slot;
   b->idesc_slot = (slot + 1) % kh_bank::IDESC_SLOTS;
@@ -526,57 +576,56 @@ int kh_bank_execute(kh_bank *b, unsigned int nblocks) {
     lo.advance(need);
     if (dp.freq_set != 0) dp.advance(need);
   }
-  if (!KH_HIP(hipMemcpyAsync(b->d_idesc, id, P * sizeof(IngestDesc), hipMemcpyHostToDevice, st))) return -1;
-  if (!KH_HIP(hipEventRecord(b->idesc_ev[slot], st))) return -1;
+  if (sf != b->front && !KH_HIP(hipStreamSynchronize(b->front))) return -1; // an earlier pipelined front half
+  // the back half that last read slot sp (two launches ago) must be done before the front half overwrites it
+  if (sf != sb && !KH_HIP(hipStreamWaitEvent(sf, b->ev_back_done[sp], 0))) return -1;
+  if (!KH_HIP(hipMemcpyAsync(b->d_idesc, id, P * sizeof(IngestDesc), hipMemcpyHostToDevice, sf))) return -1;
+  if (!KH_HIP(hipEventRecord(b->idesc_ev[slot], sf))) return -1;
 
-  bool const prof = b->profiling;
   int rc = 0;
-  if (prof || !b->use_graph) {
-    rc = enqueue(b, nblocks, prof);
+  if (prof) {
+    rc = enqueue_front(b, sf, nblocks, true);
+    if (!rc) rc = enqueue_back(b, sb, nblocks, true);
   } else {
     kh_bank::GraphEntry *g = nullptr;
     for (auto &x : b->graphs)
-      if (x.nblocks == nblocks && x.cur == b->cur && x.fmpar == b->fm_parity) g = &x;
+      if (x.nblocks == nblocks && x.cur == b->cur && x.fmpar == b->fm_parity && x.sp == sp && x.pipelined == (sf != sb))
+        g = &x;
     if (!g) { // first sight: run eagerly (this also warms the twiddle tables, which allocate)
-      b->graphs.push_back(kh_bank::GraphEntry{nblocks, b->cur, b->fm_parity, 1, nullptr});
-      rc = enqueue(b, nblocks, false);
-    } else if (g->seen < 0) {
-      rc = enqueue(b, nblocks, false);
-    } else {
-      if (!g->exec) {
-        hipGraph_t graph = nullptr;
-        bool ok = KH_HIP(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
-        if (ok) {
-          int const erc = enqueue(b, nblocks, false);
-          ok = KH_HIP(hipStreamEndCapture(st, &graph)) && erc == 0 && graph != nullptr;
-        }
-        if (ok) ok = KH_HIP(hipGraphInstantiate(&g->exec, graph, nullptr, nullptr, 0));
-        if (graph) hipGraphDestroy(graph);
-        if (!ok) {
-          g->exec = nullptr;
-          g->seen = -1;
-        }
-      }
-      if (g->exec) {
-        g->seen++;
-        rc = KH_HIP(hipGraphLaunch(g->exec, st)) ? 0 : -1;
-      } else {
-        rc = enqueue(b, nblocks, false);
+      b->graphs.push_back(kh_bank::GraphEntry{nblocks, b->cur, b->fm_parity, sp, sf != sb, 0, nullptr, nullptr});
+      g = &b->graphs.back();
+    }
+    rc = run_half(b, sf, nblocks, enqueue_front, &g->front, g->seen);
+    if (rc == -2) {
+      g->seen = -1;
+      rc = enqueue_front(b, sf, nblocks, false);
+    }
+    if (!rc && sf != sb &&
+        (!KH_HIP(hipEventRecord(b->ev_front_done[sp], sf)) || !KH_HIP(hipStreamWaitEvent(sb, b->ev_front_done[sp], 0))))
+      rc = -1;
+    if (!rc) {
+      rc = run_half(b, sb, nblocks, enqueue_back, &g->back, g->seen);
+      if (rc == -2) {
+        g->seen = -1;
+        rc = enqueue_back(b, sb, nblocks, false);
       }
     }
+    if (!rc && g->seen >= 0) g->seen++;
   }
   if (rc) return rc;
+  if (sf != sb && !KH_HIP(hipEventRecord(b->ev_back_done[sp], sb))) return -1;
   if (b->n_fm) b->fm_parity ^= 1;
   b->cur ^= 1;
+  b->last_sp = sp;
+  b->sp ^= 1;
   // consume the raw ring
   for (int i = 0; i < P; i++) {
     size_t const rest = b->fill[i] - need;
     if (rest) {
       unsigned char *base = b->d_raw + i * b->raw_stride;
-      // rest < need is not guaranteed: stage through the (now idle) tmp-free path with an ordered device copy
-      if (rest <= need) {
+      if (rest <= need) { // source and destination do not overlap; ordered behind the ingest on its stream
         if (!KH_HIP(hipMemcpyAsync(base, base + payload_bytes(b->cfg.payload, need), payload_bytes(b->cfg.payload, rest),
-                                   hipMemcpyDeviceToDevice, st)))
+                                   hipMemcpyDeviceToDevice, sf)))
           return -1;
       } else {
         set_error("kh_bank_execute: more than one launch of samples queued; consume them first");
@@ -587,10 +636,11 @@ int kh_bank_execute(kh_bank *b, unsigned int nblocks) {
   }
   b->last_blocks = nblocks;
   if (prof) {
-    if (!KH_HIP(hipStreamSynchronize(st))) return -1;
+    if (!KH_HIP(hipStreamSynchronize(sb))) return -1;
+    static int const first[KH_STAGE_COUNT] = {0, 1, 2, 3, 4, 5, -1}; // stage s = ev[first[s]] .. ev[first[s]+1]
     for (int s = 0; s < KH_STAGE_COUNT; s++) {
       float ms = 0.f;
-      if (hipEventElapsedTime(&ms, b->ev[s], b->ev[s + 1]) == hipSuccess) {
+      if (first[s] >= 0 && hipEventElapsedTime(&ms, b->ev[first[s]], b->ev[first[s] + 1]) == hipSuccess) {
         b->stage_ms[s] += ms;
         b->stage_n[s]++;
       }
@@ -601,6 +651,7 @@ int kh_bank_execute(kh_bank *b, unsigned int nblocks) {
 
 int kh_bank_sync(kh_bank *b) {
   if (!b) return -1;
+  if (!KH_HIP(hipStreamSynchronize(b->front))) return -1;
   return KH_HIP(hipStreamSynchronize(b->stream)) ? 0 : -1;
 }
 
@@ -631,7 +682,7 @@ int kh_bank_read_input_status(kh_bank *b, unsigned int input, struct kh_input_st
 }
 int kh_bank_read_spectrum(kh_bank *b, unsigned int input, unsigned int block, kh_cf32 *out) {
   if (!b || input >= (unsigned)b->P || block >= (unsigned)b->T || !out) return -1;
-  return read_back(b, out, b->d_spec + input * b->spec_stride + (size_t)block * b->N, b->N * sizeof(float2));
+  return read_back(b, out, b->d_spec[b->last_sp] + input * b->spec_stride + (size_t)block * b->N, b->N * sizeof(float2));
 }
 int kh_bank_read_response(kh_bank *b, unsigned int ch, kh_cf32 *out, float *noise_gain_out) {
   if (!b || ch >= (unsigned)b->C) return -1;
@@ -667,6 +718,7 @@ int kh_bank_use_graph(kh_bank *b, int enable) {
 }
 int kh_bank_profile(kh_bank *b, int enable) {
   if (!b) return -1;
+  if (kh_bank_sync(b)) return -1; // the two modes order their work differently
   b->profiling = enable != 0;
   memset(b->stage_ms, 0, sizeof(b->stage_ms));
   memset(b->stage_n, 0, sizeof(b->stage_n));

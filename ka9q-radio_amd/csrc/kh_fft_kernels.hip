@@ -10,6 +10,7 @@
 #include "kh_fft.cuh"
 #include "kh_regfft.cuh"
 #include "kh_fm.cuh"
+#include <cstdlib>
 
 namespace kh {
 
@@ -476,7 +477,7 @@ __global__ __launch_bounds__(NT) void kh_filter_out(const float2 *__restrict__ s
       var = block_sum<NT>(var, red) / (olen - 1);
       float2 const first = y[0], last = y[olen - 1];
       float snr = 0.f;
-      if (tid < 64) snr = (float)fm_snr_wave((double)(avg * avg / var), tid); // wave 0, cooperatively (NT >= 64)
+      if (tid < 64) snr = (float)fm_snr((double)(avg * avg / var)); // wave 0 (NT >= 64)
       __syncthreads(); // first/last are read before fm_front overwrites the block
       const DemodDesc *dd = fm.descs + ch;
       size_t const rec = (size_t)ch * fm.stat_stride + b;
@@ -501,12 +502,16 @@ static int launch_fo(hipStream_t st, const float2 *spec, size_t spec_in_stride, 
 
 int launch_filter_output(hipStream_t st, const float2 *spec, size_t spec_in_stride, int N, int in_real,
                          const ChanDesc *chans, const float2 *response, int ND, int olen, void *out, size_t out_stride,
-                         int nblocks, int nchan, FmFront const &fm) {
+                         int nblocks, int nchan, FmFront const &fm, int complex_out) {
   if (nblocks <= 0 || nchan <= 0) return 0;
   if (olen > ND || ND > N) {
     set_error("filter output: olen %d > N_dec %d or N_dec > N %d", olen, ND, N);
     return -1;
   }
+  static int const wave_env = getenv("KA9Q_HIP_CHAN_WAVE") ? atoi(getenv("KA9Q_HIP_CHAN_WAVE")) : 1; // A/B switch
+  if (wave_env && complex_out && !in_real && chan_wave_supported(ND, olen))
+    return launch_chan_wave(st, spec, spec_in_stride, N, chans, response, ND, olen, static_cast<float2 *>(out), out_stride,
+                            nblocks, nchan, fm);
 #define FO(n) \
   case n: return launch_fo<n>(st, spec, spec_in_stride, N, in_real, chans, response, olen, out, out_stride, nblocks, nchan, fm)
   switch (ND) {

@@ -3,6 +3,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include "kh_internal.h"
+#include "kh_fm_xi_cheb.h"
 
 namespace kh {
 static __device__ double fm_i0(double z) { // fm.c:152-163
@@ -32,6 +33,29 @@ static __device__ double fm_xi(double thetasq) { // fm.c:180-186
   t *= t;
   return 2 + thetasq - (0.125 * M_PI) * exp(-0.5 * thetasq) * t;
 }
+// fm_xi on [0, 100] from a piecewise Chebyshev expansion (tools/fit_fm_xi.py; within 6e-13 of the series above):
+// ~50 fp64 operations instead of two 40-term series with a division per term and an exp.  fm_snr's fixed-point
+// iteration below runs it 3 times for a strong signal, 30 and more for a block of noise (r just above pi/(4-pi)),
+// all of it on one lane's critical path.  Outside [0, 100] (never reached from fm_snr) the series is used.
+static __constant__ double kh_xi_edges[KH_XI_SEGS + 1] = KH_XI_EDGES;
+static __constant__ double kh_xi_coeffs[KH_XI_SEGS][KH_XI_DEG + 1] = KH_XI_COEFFS;
+static __device__ double fm_xi_fast(double thetasq) {
+  if (!(thetasq >= 0.0 && thetasq <= 100.0)) return fm_xi(thetasq);
+  int seg = 0;
+#pragma unroll
+  for (int k = 1; k < KH_XI_SEGS; k++) seg += thetasq > kh_xi_edges[k];
+  double const a = kh_xi_edges[seg], b = kh_xi_edges[seg + 1];
+  double const x = (2.0 * thetasq - a - b) / (b - a);
+  const double *c = kh_xi_coeffs[seg];
+  double b1 = 0.0, b2 = 0.0;
+#pragma unroll
+  for (int k = KH_XI_DEG; k >= 1; k--) { // Clenshaw
+    double const t = fma(2.0 * x, b1, c[k] - b2);
+    b2 = b1;
+    b1 = t;
+  }
+  return fma(x, b1, c[0] - b2);
+}
 static __device__ double fm_snr(double r) { // fm.c:190-205
   double thetasq = r;
   double othetasq = r + 10;
@@ -40,58 +64,11 @@ static __device__ double fm_snr(double r) { // fm.c:190-205
   int guard = 0; // the reference loop has no bound; NaN input falls through both tests above and exits here
   while (fabs(thetasq - othetasq) > .001 && guard++ < 10000) {
     othetasq = thetasq;
-    thetasq = fm_xi(thetasq) * (1 + r) - 2;
+    thetasq = fm_xi_fast(thetasq) * (1 + r) - 2;
   }
   return thetasq;
 }
 
-
-// fm_snr evaluated by one whole wavefront (all 64 lanes call it with the same r and get the same result).
-// The two Bessel series of fm.c:152-179 are 40-term products of per-term factors, i.e. a multiplicative scan
-// over lanes followed by a sum.  The reference's early exit (term < 1e-12 * sum) only drops terms below
-// 1e-12 of the sum, so summing all 40 terms changes the result by less than that.
-static __device__ __forceinline__ double fm_wave_sum(double v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-  return v;
-}
-static __device__ double fm_xi_wave(double thetasq, int lane) { // fm.c:180-186 with fm.c:152-179 inlined
-  double const z = 0.25 * thetasq;
-  double const t = 0.25 * (z * z);
-  // lane k holds the factor that takes term k-1 to term k (k < 40); lanes >= 40 hold zero terms
-  double f0 = 1.0, f1 = 1.0;
-  if (lane >= 1) {
-    double const dk = (double)lane;
-    f0 = t / (dk * dk);         // i0: term_k = term_{k-1} * t/(k*k), term_1 = t
-    f1 = t / (dk * (dk + 1.0)); // i1: term_k = term_{k-1} * t/(k*(k+1)), term_1 = 0.5*t
-  }
-#pragma unroll
-  for (int o = 1; o < 64; o <<= 1) {
-    double const p0 = __shfl_up(f0, o, 64), p1 = __shfl_up(f1, o, 64);
-    if (lane >= o) {
-      f0 *= p0;
-      f1 *= p1;
-    }
-  }
-  if (lane >= 40) f0 = 0.0, f1 = 0.0;
-  double const i0 = fm_wave_sum(f0);
-  double const i1 = 0.5 * z * fm_wave_sum(f1);
-  double tt = (2 + thetasq) * i0 + thetasq * i1;
-  tt *= tt;
-  return 2 + thetasq - (0.125 * M_PI) * exp(-0.5 * thetasq) * tt;
-}
-static __device__ double fm_snr_wave(double r, int lane) { // fm.c:190-205
-  double thetasq = r;
-  double othetasq = r + 10;
-  if (r <= M_PI / (4 - M_PI)) return 0;
-  if (r > 100) return r;
-  int guard = 0;
-  while (fabs(thetasq - othetasq) > .001 && guard++ < 10000) {
-    othetasq = thetasq;
-    thetasq = fm_xi_wave(thetasq, lane) * (1 + r) - 2;
-  }
-  return thetasq;
-}
 
 // block-wide sum for workgroups of NT threads (NT a multiple of 64, <= 1024); `red` holds NT/64 floats.
 // Every thread gets the total.  Two barriers.

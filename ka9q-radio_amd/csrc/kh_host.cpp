@@ -389,7 +389,7 @@ int execute_filter_output(struct filter_out *slave, int rotate) {
   o->chan->fm_stats = 0;
   if (!rc)
     rc = launch_filter_output(o->stream, im->d_spec[blk & 1], 0, o->N, master->in_type == REAL, o->chan,
-                              o->d_resp[o->active], o->ND, o->olen, o->d_out, 0, 1, 1, FmFront{});
+                              o->d_resp[o->active], o->ND, o->olen, o->d_out, 0, 1, 1, FmFront{}, out_type != REAL);
   if (!rc) {
     if (out_type == REAL)
       rc = KH_HIP(hipMemcpyAsync(slave->output.r, o->d_out, o->olen * sizeof(float), hipMemcpyDeviceToHost, o->stream))

@@ -120,9 +120,15 @@ int launch_forward_fft(hipStream_t st, const void *time, size_t in_stride, int r
                        size_t spec_in_stride, int N, int L, int nblocks, int ninputs, hipEvent_t mid_event, N0Fuse n0);
 // bin-select x response x inverse transform.  out: cf32 (or f32 when out_type REAL) at
 // out + ch*out_stride + b*olen.
+// complex_out: 1 if no channel has out_type REAL (known on the host): shapes that have one then take the
+// wave-resident kernel of kh_chan_kernels.hip.
 int launch_filter_output(hipStream_t st, const float2 *spec, size_t spec_in_stride, int N, int in_real,
                          const ChanDesc *chans, const float2 *response, int ND, int olen, void *out, size_t out_stride,
-                         int nblocks, int nchan, FmFront const &fm);
+                         int nblocks, int nchan, FmFront const &fm, int complex_out);
+int chan_wave_supported(int ND, int olen);
+int launch_chan_wave(hipStream_t st, const float2 *spec, size_t spec_in_stride, int N, const ChanDesc *chans,
+                     const float2 *response, int ND, int olen, float2 *out, size_t out_stride, int nblocks, int nchan,
+                     FmFront const &fm);
 // wire format -> cf32 * gain * Doppler * LO2 and per-block energy (radio.c:136-191)
 // energy_part: ingest_chunks(L) floats per (input, block), summed by launch_n0
 int ingest_chunks(int L);
