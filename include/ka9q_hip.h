@@ -218,8 +218,9 @@ int kh_bank_keep_audio(kh_bank *, int enable);
  * output straight to the discriminator inside one kernel and only PCM + status leave it.  Channels with another
  * demodulator (or none) always store it. */
 int kh_bank_keep_baseband(kh_bank *, int enable);
-/* 1 (default): the kernel sequence of kh_bank_execute is captured into a hipGraph the second time a launch shape
- * (nblocks, buffer parity) is seen and replayed from then on: one host call per launch.  0: plain launches. */
+/* 1: the two halves of kh_bank_execute's kernel sequence are captured into hipGraphs the second time a launch shape
+ * (nblocks, buffer parity) is seen and replayed from then on.  0 (default): plain launches -- with four to six
+ * kernels per launch the replay costs the host more than the launches do (measured, tools/hostbound.py). */
 int kh_bank_use_graph(kh_bank *, int enable);
 void *kh_bank_stream(kh_bank *); /* hipStream_t */
 /* per-kernel timing with HIP events on the bank's stream.  Stages: */

@@ -13,10 +13,12 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <algorithm>
 #include <vector>
 
 #include "../../include/ka9q_hip.h"
 #include "kh_internal.h"
+#include "kh_n0.cuh"
 
 using namespace kh;
 
@@ -56,8 +58,6 @@ struct kh_bank {
   kh_bank_config cfg;
   int N, ND, olen, T, C, P;
   hipStream_t stream = nullptr;
-  hipStream_t side = nullptr;             // compute_n0's second iteration runs here, beside the channel kernels
-  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   // The launch is cut in two: FRONT (convert + mix, forward FFT: streams the whole block through HBM) on `front`,
   // BACK (compute_n0, channels, demodulators: little memory traffic, latency bound) on `stream`.  Everything the
   // front hands to the back is double buffered (sp = slot of the current launch), so the front of launch k+1 runs
@@ -65,6 +65,9 @@ struct kh_bank {
   hipStream_t front = nullptr;
   hipEvent_t ev_front_done[2] = {}, ev_back_done[2] = {};
   int sp = 0, last_sp = 0, pipeline = 1;
+  int fused_ingest = 1;   // policy (KA9Q_HIP_FUSED_INGEST)
+  int ride_n0 = 1;        // policy (KA9Q_HIP_RIDE_N0)
+  bool fused_now = false; // this launch: large transform and no oscillator active
   // device
   unsigned char *d_raw = nullptr;
   size_t raw_stride = 0; // bytes per input
@@ -112,12 +115,14 @@ struct kh_bank {
   struct GraphEntry {
     unsigned nblocks;
     int cur, fmpar, sp;
-    bool pipelined;
+    bool pipelined, fused;
     int seen;              // launches seen with this key; -1: capture failed, stay eager
     hipGraphExec_t front, back;
   };
   std::vector<GraphEntry> graphs;
-  int use_graph = 1, use_side = 1;
+  // measured on MI355X (tools/hostbound.py): replaying two small graphs costs the host more than their handful of
+  // launches, so graphs are off unless asked for
+  int use_graph = 0;
   // profiling
   bool profiling = false;
   hipEvent_t ev[KH_STAGE_COUNT + 2] = {};
@@ -140,7 +145,6 @@ extern "C" {
 int kh_bank_destroy(kh_bank *b) {
   if (!b) return 0;
   if (b->stream) hipStreamSynchronize(b->stream);
-  if (b->side) hipStreamSynchronize(b->side);
   if (b->front) hipStreamSynchronize(b->front);
   drop_graphs(b);
   void *ptrs[] = {b->d_raw,   b->d_time[0], b->d_time[1], b->d_spec[0], b->d_spec[1], b->d_tmp, b->d_chans, b->d_resp,
@@ -155,13 +159,10 @@ int kh_bank_destroy(kh_bank *b) {
   for (auto &e : b->idesc_ev)
     if (e) hipEventDestroy(e);
   if (b->h_idesc) hipHostFree(b->h_idesc);
-  if (b->ev_fork) hipEventDestroy(b->ev_fork);
-  if (b->ev_join) hipEventDestroy(b->ev_join);
   for (auto &e : b->ev_front_done)
     if (e) hipEventDestroy(e);
   for (auto &e : b->ev_back_done)
     if (e) hipEventDestroy(e);
-  if (b->side) hipStreamDestroy(b->side);
   if (b->front) hipStreamDestroy(b->front);
   if (b->stream) hipStreamDestroy(b->stream);
   delete b;
@@ -206,15 +207,25 @@ kh_bank *kh_bank_create(const struct kh_bank_config *cfg) {
   b->C = cfg->n_channels;
   b->P = cfg->n_inputs;
   size_t const T = b->T, C = b->C, P = b->P, L = cfg->L, M = cfg->M;
-  bool ok = KH_HIP(hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking));
-  ok = ok && KH_HIP(hipStreamCreateWithFlags(&b->side, hipStreamNonBlocking));
-  ok = ok && KH_HIP(hipStreamCreateWithFlags(&b->front, hipStreamNonBlocking));
+  bool ok = true;
+  // The back half is short, latency-bound kernels; the front half fills the chip with workgroups.  With equal
+  // priorities the dispatcher drains the front kernel before it looks at the other queue (measured: 14 us of overlap
+  // out of 44); the back stream therefore gets the higher priority.  KA9Q_HIP_PRIO=0 turns that off.
+  int prio_lo = 0, prio_hi = 0;
+  hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi); // lowest, greatest (numerically smaller = higher)
+  bool use_prio = prio_lo != prio_hi;
+  if (const char *e = getenv("KA9Q_HIP_PRIO")) use_prio = use_prio && atoi(e) != 0;
+  if (use_prio) {
+    ok = ok && KH_HIP(hipStreamCreateWithPriority(&b->stream, hipStreamNonBlocking, prio_hi));
+    ok = ok && KH_HIP(hipStreamCreateWithPriority(&b->front, hipStreamNonBlocking, prio_lo));
+  } else {
+    ok = ok && KH_HIP(hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking));
+    ok = ok && KH_HIP(hipStreamCreateWithFlags(&b->front, hipStreamNonBlocking));
+  }
   for (auto &e : b->ev_front_done) ok = ok && KH_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
   for (auto &e : b->ev_back_done) ok = ok && KH_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
   ok = ok && KH_HIP(hipHostMalloc((void **)&b->h_idesc, kh_bank::IDESC_SLOTS * P * sizeof(IngestDesc), hipHostMallocDefault));
   for (auto &e : b->idesc_ev) ok = ok && KH_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-  ok = ok && KH_HIP(hipEventCreateWithFlags(&b->ev_fork, hipEventDisableTiming));
-  ok = ok && KH_HIP(hipEventCreateWithFlags(&b->ev_join, hipEventDisableTiming));
   b->raw_stride = (payload_bytes(cfg->payload, T * L) + 15) & ~(size_t)15;
   b->time_stride = ((M - 1) + T * L + 1) & ~(size_t)1;
   b->spec_stride = T * N;
@@ -242,7 +253,7 @@ kh_bank *kh_bank_create(const struct kh_bank_config *cfg) {
   A(&b->d_status, C * T * sizeof(kh_status), true);
   A(&b->d_istatus, P * T * sizeof(kh_input_status), true);
   for (int k = 0; k < 2; k++) {
-    A(&b->d_energy[k], P * T * ingest_chunks(cfg->L) * sizeof(float), true);
+    A(&b->d_energy[k], P * T * std::max(ingest_chunks(cfg->L), fused_ingest_tiles(N)) * sizeof(float), true);
     A(&b->d_n0acc[k], n0_part_floats() * P * T * sizeof(float), true);
   }
   A(&b->d_n0state, P * sizeof(float), false);
@@ -272,8 +283,9 @@ kh_bank *kh_bank_create(const struct kh_bank_config *cfg) {
     return nullptr;
   }
   if (const char *e = getenv("KA9Q_HIP_GRAPH")) b->use_graph = atoi(e);
-  if (const char *e = getenv("KA9Q_HIP_SIDE")) b->use_side = atoi(e);
   if (const char *e = getenv("KA9Q_HIP_PIPELINE")) b->pipeline = atoi(e);
+  if (const char *e = getenv("KA9Q_HIP_FUSED_INGEST")) b->fused_ingest = atoi(e);
+  if (const char *e = getenv("KA9Q_HIP_RIDE_N0")) b->ride_n0 = atoi(e);
   b->chans.assign(C, ChanDesc{0, 0, COMPLEX, 0});
   b->ddesc.assign(C, DemodDesc{});
   b->ccfg.assign(C, kh_channel_config{});
@@ -474,19 +486,24 @@ static int enqueue_front(kh_bank *b, hipStream_t st, unsigned int nblocks, bool 
   // the last M-1 samples of the launch are the next launch's overlap-save history (filter.c:230): ingest stores
   // them at the head of the other buffer as it goes, unless the history reaches back beyond this launch
   bool const fused_carry = (size_t)(M - 1) <= need;
-  if (launch_ingest(st, b->d_raw, b->raw_stride, b->cfg.payload, time + (M - 1), b->time_stride, b->d_idesc,
-                    b->d_energy[sp], L, nblocks, P, fused_carry ? b->d_time[b->cur ^ 1] : nullptr,
-                    need - (fused_carry ? (M - 1) : 0)))
+  // large transforms read the raw ring themselves (fused convert + IF power + history) unless an oscillator is active
+  bool const fused = b->fused_now;
+  FftIngest const fi{b->d_raw, b->raw_stride, (unsigned)payload_bytes(b->cfg.payload, (size_t)b->T * L), b->cfg.payload,
+                     time, b->d_time[b->cur ^ 1], b->time_stride, b->d_idesc, b->d_energy[sp], M};
+  if (!fused && launch_ingest(st, b->d_raw, b->raw_stride, b->cfg.payload, time + (M - 1), b->time_stride, b->d_idesc,
+                              b->d_energy[sp], L, nblocks, P, fused_carry ? b->d_time[b->cur ^ 1] : nullptr,
+                              need - (fused_carry ? (M - 1) : 0)))
     return -1;
   if (prof) hipEventRecord(b->ev[1], st);
   // launch_forward_fft records the mid event (ev[2]) between the two passes itself
   N0Plan const plan = n0_plan(N, b->cfg.samprate, b->cfg.n0_low, b->cfg.n0_high);
   bool const n0_on = b->cfg.compute_n0 && plan.valid;
   if (launch_forward_fft(st, time, b->time_stride, 0, b->d_spec[sp], b->d_tmp, b->spec_stride, N, L, nblocks, P,
-                         prof ? b->ev[2] : nullptr, N0Fuse{n0_on ? b->d_n0acc[sp] : nullptr, plan.start, plan.bincount}))
+                         prof ? b->ev[2] : nullptr, N0Fuse{n0_on ? b->d_n0acc[sp] : nullptr, plan.start, plan.bincount},
+                         fused ? &fi : nullptr))
     return -1;
   // overlap-save history for the next call (filter.c:230), into the other buffer
-  if (!fused_carry && launch_carry(st, time + need, b->d_time[b->cur ^ 1], b->time_stride * sizeof(float2),
+  if (!fused && !fused_carry && launch_carry(st, time + need, b->d_time[b->cur ^ 1], b->time_stride * sizeof(float2),
                                    (size_t)(M - 1) * sizeof(float2), P))
     return -1;
   if (prof) hipEventRecord(b->ev[3], st);
@@ -496,21 +513,26 @@ static int enqueue_front(kh_bank *b, hipStream_t st, unsigned int nblocks, bool 
 static int enqueue_back(kh_bank *b, hipStream_t st, unsigned int nblocks, bool prof) {
   int const L = b->cfg.L, N = b->N, P = b->P, C = b->C, sp = b->sp;
   N0Plan const plan = n0_plan(N, b->cfg.samprate, b->cfg.n0_low, b->cfg.n0_high);
-  // compute_n0's second iteration and the smoothing only read the spectrum: they run on the side stream while the
-  // channel kernels run on this one (joined below).  With per-stage timing on, everything stays on one stream.
-  bool const fork = !prof && b->use_side;
-  hipStream_t const sn = fork ? b->side : st;
-  if (fork && (!KH_HIP(hipEventRecord(b->ev_fork, st)) || !KH_HIP(hipStreamWaitEvent(sn, b->ev_fork, 0)))) return -1;
-  if (launch_n0(sn, b->cfg.compute_n0 ? b->d_spec[sp] : nullptr, b->spec_stride, N, b->cfg.samprate, plan, b->d_energy[sp],
-                L, b->d_n0state, b->d_n0acc[sp], b->d_istatus, nblocks, P))
+  // compute_n0's second iteration (radio.c:451-462) only reads the spectrum: it rides along in the channel kernel's
+  // launch when that kernel is the wave-resident one; otherwise it is a kernel of its own, in front.
+  int const echunks = b->fused_now ? fused_ingest_tiles(N) : ingest_chunks(L);
+  const float2 *n0spec = b->cfg.compute_n0 ? b->d_spec[sp] : nullptr;
+  N0Pass1Args z;
+  bool const ride = b->ride_n0 && chan_wave_supported(b->ND, b->olen) &&
+                    n0_pass1_args(&z, n0spec, b->spec_stride, N, plan, b->d_n0acc[sp], nblocks, P);
+  if (!ride && launch_n0(st, n0spec, b->spec_stride, N, b->cfg.samprate, plan, b->d_energy[sp], echunks, L, b->d_n0state,
+                         b->d_n0acc[sp], b->d_istatus, nblocks, P))
     return -1;
-  if (fork && !KH_HIP(hipEventRecord(b->ev_join, sn))) return -1;
   if (prof) hipEventRecord(b->ev[4], st);
+  int taken = 0;
   if (launch_filter_output(st, b->d_spec[sp], b->spec_stride, N, 0, b->d_chans, b->d_resp, b->ND, b->olen, b->d_bb,
                            b->bb_stride, nblocks, C,
                            FmFront{b->n_fm ? b->d_fmstat : nullptr, b->d_fmwork, b->d_fmcarry, b->d_ddesc, b->T, b->bb_stride,
                                    b->keep_baseband},
-                           1))
+                           1, ride ? &z : nullptr, &taken))
+    return -1;
+  if (ride && launch_n0(st, n0spec, b->spec_stride, N, b->cfg.samprate, plan, b->d_energy[sp], echunks, L, b->d_n0state,
+                        b->d_n0acc[sp], b->d_istatus, nblocks, P, taken))
     return -1;
   if (prof) hipEventRecord(b->ev[5], st);
   if (launch_demod(st, b->d_bb, b->bb_stride, b->olen, nblocks, C, b->d_ddesc, b->d_dstate,
@@ -519,7 +541,6 @@ static int enqueue_back(kh_bank *b, hipStream_t st, unsigned int nblocks, bool p
                    FmScratch{b->d_fmstat, b->d_fmwork, b->d_fmcarry, b->d_decaypow, b->fm_parity}))
     return -1;
   if (prof) hipEventRecord(b->ev[6], st);
-  if (fork && !KH_HIP(hipStreamWaitEvent(st, b->ev_join, 0))) return -1;
   return 0;
 }
 
@@ -576,6 +597,9 @@ int kh_bank_execute(kh_bank *b, unsigned int nblocks) {
     lo.advance(need);
     if (dp.freq_set != 0) dp.advance(need);
   }
+  b->fused_now = b->fused_ingest && b->N > KH_MAX_SMALL_N;
+  for (int i = 0; i < P; i++)
+    if (id[i].lo2.active || id[i].doppler.active) b->fused_now = false;
   if (sf != b->front && !KH_HIP(hipStreamSynchronize(b->front))) return -1; // an earlier pipelined front half
   // the back half that last read slot sp (two launches ago) must be done before the front half overwrites it
   if (sf != sb && !KH_HIP(hipStreamWaitEvent(sf, b->ev_back_done[sp], 0))) return -1;
@@ -589,10 +613,11 @@ int kh_bank_execute(kh_bank *b, unsigned int nblocks) {
   } else {
     kh_bank::GraphEntry *g = nullptr;
     for (auto &x : b->graphs)
-      if (x.nblocks == nblocks && x.cur == b->cur && x.fmpar == b->fm_parity && x.sp == sp && x.pipelined == (sf != sb))
+      if (x.nblocks == nblocks && x.cur == b->cur && x.fmpar == b->fm_parity && x.sp == sp && x.pipelined == (sf != sb) &&
+          x.fused == b->fused_now)
         g = &x;
     if (!g) { // first sight: run eagerly (this also warms the twiddle tables, which allocate)
-      b->graphs.push_back(kh_bank::GraphEntry{nblocks, b->cur, b->fm_parity, sp, sf != sb, 0, nullptr, nullptr});
+      b->graphs.push_back(kh_bank::GraphEntry{nblocks, b->cur, b->fm_parity, sp, sf != sb, b->fused_now, 0, nullptr, nullptr});
       g = &b->graphs.back();
     }
     rc = run_half(b, sf, nblocks, enqueue_front, &g->front, g->seen);

@@ -1,4 +1,4 @@
-// kh_chan_kernels.hip -- filter output for complex channels with N_dec = R*R and olen = N_dec/2, wave-resident.
+// kh_chan_kernels.hip -- filter output for complex channels with N_dec = 1024 and olen = N_dec/2, wave-resident.
 //
 // Reference behaviour restated here (citations into the reference tree):
 //   execute_filter_output  filter.c:240-289 (complex -> complex bin select/rotate x response), 371-382 (CROSS_CONJ
@@ -19,6 +19,7 @@
 #include "kh_fft.cuh"
 #include "kh_regfft.cuh"
 #include "kh_fm.cuh"
+#include "kh_n0.cuh"
 #include <cstdlib>
 
 namespace kh {
@@ -66,197 +67,6 @@ __device__ __forceinline__ float group_sum(float v) { // over the R lanes of a g
   return v;
 }
 
-template <int R>
-__global__ __launch_bounds__(64) void kh_chan_wave(const float2 *__restrict__ spec, size_t spec_in_stride, int N,
-                                                   const ChanDesc *__restrict__ chans,
-                                                   const float2 *__restrict__ response, float2 *__restrict__ out,
-                                                   size_t out_stride, const float2 *__restrict__ tw, FmFront fm,
-                                                   int nchan, int npairs) {
-  constexpr int ND = R * R, OLEN = ND / 2, G = 64 / R, K = R / 2;
-  constexpr int PITCH = R + 1;   // odd: the transposed reads of a group fall in R different banks
-  constexpr int PITCH2 = K + 1;  // second transpose: lane c reads K consecutive samples
-  static_assert(OLEN + OLEN / K <= R * PITCH, "second transpose fits the first one's buffer");
-  __shared__ float ex[G * R * PITCH];
-  int const lane = threadIdx.x & (R - 1), g = threadIdx.x / R;
-  float *exg = ex + g * R * PITCH;
-  int q = blockIdx.x * G + g;
-  bool const valid = q < npairs; // an odd tail: the idle group repeats the last pair and stores nothing
-  if (!valid) q = npairs - 1;
-  int const ch = q % nchan, b = q / nchan;
-  ChanDesc const cd = chans[ch];
-  const float2 *fd = spec + (size_t)cd.input * spec_in_stride + (size_t)b * N;
-  const float2 *resp = response + (size_t)ch * ND;
-
-  // ---- filter.c:274-289: f[p] = response[p] * fdomain[m], p = (ND/2+1+i) mod ND, m = (N-ND/2+1+rotate+i) mod N
-  int m0 = N - ND / 2 + 1 + cd.rotate;
-  if (m0 >= N) m0 -= N;
-  if (m0 < 0) m0 += N;
-  float2 v[R];
-#pragma unroll
-  for (int a = 0; a < R; a++) {
-    int const p = R * a + lane;
-    int const i = (p - (ND / 2 + 1)) & (ND - 1);
-    int m = m0 + i;
-    if (m >= N) m -= N;
-    v[a] = cmul(resp[p], fd[m]);
-  }
-  if (cd.out_type == CW_CROSS_CONJ) { // filter.c:371-381, on the fly: the mirrored bin is loaded as well
-#pragma unroll
-    for (int a = 0; a < R; a++) {
-      int const p = R * a + lane;
-      if (p != 0 && p != ND / 2) {
-        int const dn = ND - p;
-        int const i = (dn - (ND / 2 + 1)) & (ND - 1);
-        int m = m0 + i;
-        if (m >= N) m -= N;
-        float2 const o = cmul(resp[dn], fd[m]);
-        v[a] = p < ND / 2 ? cadd(v[a], cconj(o)) : csub(v[a], cconj(o));
-      }
-    }
-  }
-
-  // ---- backward DFT of ND = R*R points (filter.c:382): X[c + R d] = sum_b W_R^{bd} ( W_ND^{bc} sum_a f[R a + b] W_R^{ac} )
-  reg_fft<R, +1>(v);
-  chan_twiddle<R, +1>(v, tw, lane);
-  float2 z[R];
-#pragma unroll
-  for (int c = 0; c < R; c++) exg[c * PITCH + lane] = v[c].x;
-  __syncthreads();
-#pragma unroll
-  for (int bb = 0; bb < R; bb++) z[bb].x = exg[lane * PITCH + bb];
-  __syncthreads();
-#pragma unroll
-  for (int c = 0; c < R; c++) exg[c * PITCH + lane] = v[c].y;
-  __syncthreads();
-#pragma unroll
-  for (int bb = 0; bb < R; bb++) z[bb].y = exg[lane * PITCH + bb];
-  reg_fft<R, +1>(z);
-  // lane c now holds X[c + R d] in z[d]; the block's output is n >= ND - OLEN: d >= K (filter.c:197,206)
-  float2 y[K]; // sample n' = lane + R e of the block
-#pragma unroll
-  for (int e = 0; e < K; e++) y[e] = z[K + e];
-
-  bool const is_fm = fm.stat != nullptr && cd.fm_stats; // uniform over the group
-  if (valid && (!is_fm || fm.write_baseband)) {
-    float2 *o = out + (size_t)ch * out_stride + (size_t)b * OLEN;
-#pragma unroll
-    for (int e = 0; e < K; e++) o[lane + R * e] = y[e];
-  }
-  if (!is_fm) return; // (a one-wave workgroup: nobody is left waiting at a barrier)
-
-  // ---- fm.c:53-70: baseband power, amplitude mean and variance, Rice-corrected SNR
-  float amp[K];
-  float bb = 0.f, sa = 0.f;
-#pragma unroll
-  for (int e = 0; e < K; e++) {
-    float const t = y[e].x * y[e].x + y[e].y * y[e].y;
-    bb += t;
-    amp[e] = sqrtf(t);
-    sa += amp[e];
-  }
-  bb = group_sum<R>(bb);
-  sa = group_sum<R>(sa);
-  float const avg = sa / OLEN;
-  float var = 0.f;
-#pragma unroll
-  for (int e = 0; e < K; e++) var += (amp[e] - avg) * (amp[e] - avg);
-  var = group_sum<R>(var) / (OLEN - 1);
-  float const snr = fmaxf(0.0f, (float)fm_snr((double)(avg * avg / var)));
-  float2 const first = make_float2(__shfl(y[0].x, 0, R), __shfl(y[0].y, 0, R));
-  float2 const last = make_float2(__shfl(y[K - 1].x, R - 1, R), __shfl(y[K - 1].y, R - 1, R));
-
-  // ---- fm.c:85-93 for samples 1 .. OLEN-1: p = y[n] conj(y[n-1]); n-1 sits in lane-1 (lane 0: lane R-1, one row up)
-  float ang[K], wgt[K];
-  float angsum = 0.f;
-  {
-    int const src = (lane + R - 1) & (R - 1);
-    float2 up = make_float2(0.f, 0.f);
-#pragma unroll
-    for (int e = 0; e < K; e++) {
-      float2 const rot = make_float2(__shfl(y[e].x, src, R), __shfl(y[e].y, src, R));
-      float2 const prev = lane ? rot : up;
-      up = rot;
-      float2 const p = cmulc(y[e], prev);
-      float a = atan2f(p.y, p.x);              // cargf, fm.c:89
-      float w = sqrtf(p.x * p.x + p.y * p.y) / var; // cabsf(p) / fm_variance, fm.c:91
-      if (w > 1) w = 1;
-      if (e == 0 && lane == 0) a = 0.f, w = 0.f; // sample 0 needs the block before: kh_fm_finish
-      ang[e] = a;
-      wgt[e] = w;
-      angsum += a;
-    }
-  }
-  angsum = group_sum<R>(angsum);
-
-  // ---- second transpose: lane c gets samples K c .. K c + K - 1
-  float angc[K], wgtc[K];
-  __syncthreads();
-#pragma unroll
-  for (int e = 0; e < K; e++) {
-    int const n = lane + R * e;
-    exg[n + n / K] = ang[e];
-  }
-  __syncthreads();
-#pragma unroll
-  for (int j = 0; j < K; j++) angc[j] = exg[lane * PITCH2 + j];
-  __syncthreads();
-#pragma unroll
-  for (int e = 0; e < K; e++) {
-    int const n = lane + R * e;
-    exg[n + n / K] = wgt[e];
-  }
-  __syncthreads();
-#pragma unroll
-  for (int j = 0; j < K; j++) wgtc[j] = exg[lane * PITCH2 + j];
-
-  // ---- fm.c:105-111 from a ZERO carry-in: s_n = (s_{n-1} * decay) + x_n; the block's carry-out goes to kh_fm_finish
-  const DemodDesc *dd = fm.descs + ch;
-  float const gain = dd->fm_gain;
-  int const flat = dd->flat;
-  float s0[K];
-  double carry_out = 0.0;
-  if (flat) {
-#pragma unroll
-    for (int j = 0; j < K; j++) s0[j] = angc[j] * gain; // fm.c:105
-  } else {
-    double x[K];
-    double A = 1.0, B = 0.0; // this lane's chunk as the map carry_out = A*carry_in + B
-#pragma unroll
-    for (int j = 0; j < K; j++) {
-      x[j] = (double)angc[j] * .114 * (double)gain * (double)wgtc[j]; // fm.c:110
-      B = (B + x[j]) * FM_DECAY;
-      A *= FM_DECAY;
-    }
-    double Ai = A, Bi = B; // inclusive scan of the maps over the group's lanes
-#pragma unroll
-    for (int o = 1; o < R; o <<= 1) {
-      double const Ap = __shfl_up(Ai, o, R), Bp = __shfl_up(Bi, o, R);
-      if (lane >= o) {
-        Bi = Ai * Bp + Bi;
-        Ai = Ai * Ap;
-      }
-    }
-    double cin = __shfl_up(Bi, 1, R); // carry into this lane's chunk for a zero carry into the block
-    if (lane == 0) cin = 0.0;
-    carry_out = __shfl(Bi, R - 1, R);
-#pragma unroll
-    for (int j = 0; j < K; j++) {
-      cin += x[j];       // samples[n] = lastaudio += ...
-      s0[j] = (float)cin;
-      cin *= FM_DECAY;   // lastaudio *= 0.99376949
-    }
-  }
-  if (!valid) return;
-  size_t const rec = (size_t)ch * fm.stat_stride + b;
-  float4 *wo = reinterpret_cast<float4 *>(fm.work + (size_t)ch * fm.work_stride + (size_t)b * OLEN + (size_t)lane * K);
-#pragma unroll
-  for (int j = 0; j < K; j += 2) wo[j / 2] = make_float4(angc[j], s0[j], angc[j + 1], s0[j + 1]);
-  if (lane == 0) {
-    fm.stat[rec] = FmBlockStat{bb / OLEN, var, snr, angsum, first, last};
-    fm.carry[rec] = carry_out;
-  }
-}
-
 // ---------------------------------------------------------------------------------------------------------------
 // One whole wavefront per (channel, block): ND = RA * 64, RA points per lane.
 //   stage A  lane b < 64: RA-point transform over a of f[64 a + b], twiddle W_ND^{b c}
@@ -267,19 +77,45 @@ __global__ __launch_bounds__(64) void kh_chan_wave(const float2 *__restrict__ sp
 // Lane l = c + RA h ends up with outputs n = l + 64 d'; the block's output (upper half) is d' >= 8: sample
 // n' = l + 64 e, e < 8: consecutive lanes hold consecutive samples.  Half the register count of the R*R form and
 // twice the waves: that is what counts while a launch has fewer (channel, block) pairs than the chip has SIMDs x 2.
+struct ChanArgs {
+  const float2 *spec;
+  size_t spec_in_stride;
+  int N;
+  const ChanDesc *chans;
+  const float2 *response;
+  float2 *out;
+  size_t out_stride;
+  const float2 *tw;
+  FmFront fm;
+  int nchan, npairs;
+};
+constexpr int CW_RA = 16, CW_PITCH = 64 + 1;    // rows of 64 complex points, pitch in float2
+constexpr int CW_LDS = CW_RA * CW_PITCH;        // float2 per wave
+
+// the wave's barrier: LDS operations of one wave execute in order, so all that is needed between a transposing write
+// and its read is that the compiler keeps them apart (several of these waves share a workgroup with compute_n0's
+// second pass in kh_back_a: a workgroup barrier would tie them together for nothing)
+__device__ __forceinline__ void wave_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
 template <int RA>
-__global__ __launch_bounds__(64) void kh_chan_wave64(const float2 *__restrict__ spec, size_t spec_in_stride, int N,
-                                                     const ChanDesc *__restrict__ chans,
-                                                     const float2 *__restrict__ response, float2 *__restrict__ out,
-                                                     size_t out_stride, const float2 *__restrict__ tw, FmFront fm,
-                                                     int nchan) {
+__device__ __forceinline__ void chan_wave64_body(ChanArgs const &A, float2 *ex /*CW_LDS of this wave*/, int q, int lane) {
   static_assert(RA == 16, "64 lanes = RA rows x 4 splits");
   constexpr int RB = 64, ND = RA * RB, OLEN = ND / 2, K = OLEN / 64; // K = 8 samples per lane
-  constexpr int PITCH = RB + 1;  // in float2: rows start in different banks
-  constexpr int PITCH2 = K + 1;  // second transpose, in floats
-  __shared__ float2 ex[RA * PITCH];
-  int const lane = threadIdx.x;
-  int const ch = blockIdx.x % nchan, b = blockIdx.x / nchan;
+  constexpr int PITCH = CW_PITCH; // in float2: rows start in different banks
+  constexpr int PITCH2 = K + 1;   // second transpose, in floats
+  const float2 *__restrict__ spec = A.spec;
+  const float2 *__restrict__ response = A.response;
+  const float2 *__restrict__ tw = A.tw;
+  float2 *__restrict__ out = A.out;
+  FmFront const &fm = A.fm;
+  int const N = A.N, nchan = A.nchan;
+  size_t const spec_in_stride = A.spec_in_stride, out_stride = A.out_stride;
+  int const ch = q % nchan, b = q / nchan;
+  const ChanDesc *chans = A.chans;
   ChanDesc const cd = chans[ch];
   const float2 *fd = spec + (size_t)cd.input * spec_in_stride + (size_t)b * N;
   const float2 *resp = response + (size_t)ch * ND;
@@ -317,7 +153,7 @@ __global__ __launch_bounds__(64) void kh_chan_wave64(const float2 *__restrict__ 
   chan_twiddle<RA, +1>(v, tw, lane);
 #pragma unroll
   for (int c = 0; c < RA; c++) ex[c * PITCH + lane] = v[c];
-  __syncthreads();
+  wave_sync();
 
   // ---- stage B
   int const c = lane & (RA - 1), h = lane / RA;
@@ -396,22 +232,22 @@ __global__ __launch_bounds__(64) void kh_chan_wave64(const float2 *__restrict__ 
   // ---- second transpose: lane l gets samples K l .. K l + K - 1
   float *exf = reinterpret_cast<float *>(ex);
   float angc[K], wgtc[K];
-  __syncthreads();
+  wave_sync();
 #pragma unroll
   for (int e = 0; e < K; e++) {
     int const n = lane + 64 * e;
     exf[n + n / K] = ang[e];
   }
-  __syncthreads();
+  wave_sync();
 #pragma unroll
   for (int j = 0; j < K; j++) angc[j] = exf[lane * PITCH2 + j];
-  __syncthreads();
+  wave_sync();
 #pragma unroll
   for (int e = 0; e < K; e++) {
     int const n = lane + 64 * e;
     exf[n + n / K] = wgt[e];
   }
-  __syncthreads();
+  wave_sync();
 #pragma unroll
   for (int j = 0; j < K; j++) wgtc[j] = exf[lane * PITCH2 + j];
 
@@ -462,12 +298,34 @@ __global__ __launch_bounds__(64) void kh_chan_wave64(const float2 *__restrict__ 
   }
 }
 
+
+// one wavefront per workgroup (filter.h API path, and banks without compute_n0)
+__global__ __launch_bounds__(64) void kh_chan_wave64(ChanArgs A) {
+  __shared__ float2 ex[CW_LDS];
+  chan_wave64_body<CW_RA>(A, ex, blockIdx.x, threadIdx.x);
+}
+
+// Horizontal fusion for the bank: workgroups [0, nchan_wg) carry four (channel, block) wavefronts each, the rest are
+// compute_n0's second iteration (radio.c:451-462, kh_n0.cuh) over N0_GX slices per (input, block).  The channel
+// waves wait on memory latency and use little bandwidth, the n0 workgroups stream the spectrum: in one launch they
+// share the chip instead of queueing behind one another.
+__global__ __launch_bounds__(256) void kh_back_a(ChanArgs A, N0Pass1Args Z, int nchan_wg) {
+  __shared__ float2 ex[4 * CW_LDS];
+  if ((int)blockIdx.x < nchan_wg) {
+    int const wave = threadIdx.x >> 6;
+    int const q = blockIdx.x * 4 + wave;
+    if (q < A.npairs) chan_wave64_body<CW_RA>(A, ex + wave * CW_LDS, q, threadIdx.x & 63);
+  } else {
+    n0_pass1_body(Z, blockIdx.x - nchan_wg, reinterpret_cast<float *>(ex));
+  }
+}
+
 // R*R == ND; 0 if this shape has no wave-resident kernel (the caller falls back to kh_filter_out)
 int chan_wave_supported(int ND, int olen) { return ND == 1024 && olen * 2 == ND; }
 
 int launch_chan_wave(hipStream_t st, const float2 *spec, size_t spec_in_stride, int N, const ChanDesc *chans,
                      const float2 *response, int ND, int olen, float2 *out, size_t out_stride, int nblocks, int nchan,
-                     FmFront const &fm) {
+                     FmFront const &fm, const N0Pass1Args *n0) {
   if (!chan_wave_supported(ND, olen)) {
     set_error("wave-resident filter output: N_dec %d / olen %d unsupported", ND, olen);
     return -1;
@@ -476,15 +334,13 @@ int launch_chan_wave(hipStream_t st, const float2 *spec, size_t spec_in_stride, 
   const float2 *tw = twiddle_table(ND);
   if (!tw) return -1;
   int const npairs = nchan * nblocks;
-  static int const variant = getenv("KA9Q_HIP_CHAN_VARIANT") ? atoi(getenv("KA9Q_HIP_CHAN_VARIANT")) : 64;
-  if (variant == 64) {
-    hipLaunchKernelGGL((kh_chan_wave64<16>), dim3(npairs), dim3(64), 0, st, spec, spec_in_stride, N, chans, response, out,
-                       out_stride, tw, fm, nchan);
-    return KH_HIP(hipGetLastError()) ? 0 : -1;
+  ChanArgs const A{spec, spec_in_stride, N, chans, response, out, out_stride, tw, fm, nchan, npairs};
+  if (n0) {
+    int const nchan_wg = (npairs + 3) / 4;
+    hipLaunchKernelGGL(kh_back_a, dim3(nchan_wg + n0->gx * n0->nblocks * n0->ninputs), dim3(256), 0, st, A, *n0, nchan_wg);
+  } else {
+    hipLaunchKernelGGL(kh_chan_wave64, dim3(npairs), dim3(64), 0, st, A);
   }
-  constexpr int R = 32, G = 64 / R;
-  hipLaunchKernelGGL((kh_chan_wave<R>), dim3((npairs + G - 1) / G), dim3(64), 0, st, spec, spec_in_stride, N, chans,
-                     response, out, out_stride, tw, fm, nchan, npairs);
   return KH_HIP(hipGetLastError()) ? 0 : -1;
 }
 

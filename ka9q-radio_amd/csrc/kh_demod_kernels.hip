@@ -16,59 +16,15 @@
 #include "kh_internal.h"
 #include "kh_fft.cuh"
 #include "kh_fm.cuh"
+#include "kh_ingest.cuh"
+#include "kh_n0.cuh"
 #include "../../include/ka9q_hip.h"
 
 namespace kh {
 
-__device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-  return v;
-}
+__device__ __forceinline__ float wave_sum(float v) { return n0_wave_sum(v); }
 
 // ================================================================ ingest: radio.c:136-191
-__device__ __forceinline__ void nco_phasor(const NcoArgs &a, unsigned n, double &c, double &s) {
-  // step_osc (osc.c:39-50) returns p0 * prod_{k=1..n} step_k with step_k = s0 * ss^k:
-  // phase(n) = phase0 + n*freq + rate*n(n+1)/2 cycles.  Evaluated in closed form in fp64.
-  double const dn = (double)n;
-  double ph = fma(dn, a.freq, a.phase0);
-  if (a.rate != 0) ph = fma(a.rate, 0.5 * dn * (dn + 1.0), ph);
-  ph -= rint(ph);
-  sincospi(2.0 * ph, &s, &c);
-}
-
-__device__ __forceinline__ float2 load_raw(const unsigned char *raw, size_t n, int payload, float gain_factor) {
-  float const SCALE16 = 1.f / 32767.f; // radio.c:34
-  float const SCALE8 = 1.f / 127.f;    // radio.c:35
-  switch (payload) {
-  case KH_PT_IQ16LE: { // radio.c:159-167
-    short2 const v = reinterpret_cast<const short2 *>(raw)[n];
-    float const gain = SCALE16 * gain_factor;
-    return make_float2(gain * v.x, gain * v.y);
-  }
-  case KH_PT_PCM16BE: { // radio.c:148-157
-    uchar4 const v = reinterpret_cast<const uchar4 *>(raw)[n];
-    float const gain = SCALE16 * gain_factor;
-    return make_float2(gain * (short)((v.x << 8) | v.y), gain * (short)((v.z << 8) | v.w));
-  }
-  case KH_PT_IQ8: { // radio.c:169-176
-    char2 const v = reinterpret_cast<const char2 *>(raw)[n];
-    float const gain = SCALE8 * gain_factor;
-    return make_float2(gain * (signed char)v.x, gain * (signed char)v.y);
-  }
-  case KH_PT_IQ12: { // radio.c:138-146
-    const unsigned char *dp = raw + 3 * n;
-    int const d0 = dp[0], d1 = dp[1], d2 = dp[2];
-    float const gain = SCALE16 * gain_factor;
-    return make_float2(gain * (short)(((d0 << 8) | d1) & 0xfff0), gain * (short)(((d1 << 8) | d2) << 4));
-  }
-  default: { // KH_PT_CF32: already float (no wire format in the reference; gain_factor still applies)
-    float2 const v = reinterpret_cast<const float2 *>(raw)[n];
-    return make_float2(gain_factor * v.x, gain_factor * v.y);
-  }
-  }
-}
-
 // grid (chunks per block, nblocks, ninputs), 256 threads, INGEST_CHUNK/256 samples per thread
 // algorithmic bytes per sample: wire bytes read + 8 written
 // hist_dst: the other time buffer.  The last hist_len samples of the launch (n >= hist_from) are stored there as
@@ -138,47 +94,9 @@ int launch_ingest(hipStream_t st, const void *raw, size_t raw_stride_bytes, int 
 // kh_n0_final adds them up in a fixed order (no atomics: reproducible run to run) and applies the smoothing of
 // radio.c:197-202 block by block.
 // algorithmic bytes: 8*bincount
-constexpr int N0_GX = 64; // workgroups per (input, block) in kh_n0_pass1
-
-// part layout: [0, PT*N0_SLOTS) first-pass sums; then PT*N0_GX pairs {sum1, count1}   (PT = ninputs*nblocks)
-__global__ __launch_bounds__(256) void kh_n0_pass1(const float2 *__restrict__ spec, size_t spec_in_stride, int N,
-                                                   int start, int bincount, float *__restrict__ part, int nblocks,
-                                                   int npart0) {
-  __shared__ float ps[4], pc[4];
-  int const b = blockIdx.y, i = blockIdx.z;
-  const float2 *fd = spec + (size_t)i * spec_in_stride + (size_t)b * N;
-  size_t const pt = (size_t)i * nblocks + b;
-  const float *p0 = part + pt * N0_SLOTS;
-  float *p1 = part + (size_t)gridDim.z * nblocks * N0_SLOTS + pt * (2 * N0_GX);
-  // radio.c:456,461: twice the mean of iteration 0 (npart0 <= 64 partials, added in a fixed order)
-  float t = threadIdx.x < npart0 ? p0[threadIdx.x] : 0.f;
-  t = wave_sum(t);
-  if ((threadIdx.x & 63) == 0) ps[threadIdx.x >> 6] = t; // all partials sit in wave 0
-  __syncthreads();
-  float const th = (ps[0] / bincount) * 2;
-  __syncthreads();
-  float s = 0.f, c = 0.f;
-  for (int n = blockIdx.x * 256 + threadIdx.x; n < bincount; n += N0_GX * 256) {
-    int in = start + n; // radio.c:440-446
-    if (in >= N) in -= N;
-    float2 const x = fd[in];
-    float const p = x.x * x.x + x.y * x.y;
-    if (p < th) {
-      s += p;
-      c += 1.f;
-    }
-  }
-  s = wave_sum(s);
-  c = wave_sum(c);
-  if ((threadIdx.x & 63) == 0) {
-    ps[threadIdx.x >> 6] = s;
-    pc[threadIdx.x >> 6] = c;
-  }
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    p1[2 * blockIdx.x] = ps[0] + ps[1] + ps[2] + ps[3];
-    p1[2 * blockIdx.x + 1] = pc[0] + pc[1] + pc[2] + pc[3];
-  }
+__global__ __launch_bounds__(256) void kh_n0_pass1(N0Pass1Args Z) {
+  __shared__ float sh[8];
+  n0_pass1_body(Z, blockIdx.x, sh);
 }
 
 // one workgroup per input, one wave per block (16 waves: 16 blocks at a time; every lane issues all of its loads
@@ -252,10 +170,19 @@ N0Plan n0_plan(int N, int samprate, float low, float high) {
   return p;
 }
 
-// second iteration + smoothing + IF power; the forward transform has left the first-iteration partials in `part`
+// second iteration + smoothing + IF power; the forward transform has left the first-iteration partials in `part`.
+// n0_pass1_args: what the second iteration needs (valid == 0: compute_n0 off or no bins); the bank hands it to
+// launch_chan_wave so that the iteration shares the channel kernel's launch, and then calls launch_n0 with
+// pass1_done = 1 for the rest.
+int n0_pass1_args(N0Pass1Args *z, const float2 *spec, size_t spec_in_stride, int N, N0Plan plan, float *part, int nblocks,
+                  int ninputs) {
+  if (spec == nullptr || !plan.valid) return 0;
+  *z = N0Pass1Args{spec, spec_in_stride, N, plan.start, plan.bincount, part, nblocks, ninputs, n0_partials(N), N0_GX};
+  return 1;
+}
 int launch_n0(hipStream_t st, const float2 *spec, size_t spec_in_stride, int N, int samprate, N0Plan plan,
-              const float *energy_part, int L, float *n0_state, float *part, void *input_status, int nblocks,
-              int ninputs) {
+              const float *energy_part, int echunks, int L, float *n0_state, float *part, void *input_status, int nblocks,
+              int ninputs, int pass1_done) {
   if (nblocks <= 0 || ninputs <= 0) return 0;
   if (nblocks > N0_MAXB) {
     set_error("at most %d blocks per launch", N0_MAXB);
@@ -263,11 +190,11 @@ int launch_n0(hipStream_t st, const float2 *spec, size_t spec_in_stride, int N, 
   }
   kh_input_status *status = static_cast<kh_input_status *>(input_status);
   int const have_n0 = spec != nullptr;
-  int const valid = have_n0 && plan.valid;
-  if (valid)
-    hipLaunchKernelGGL(kh_n0_pass1, dim3(N0_GX, nblocks, ninputs), dim3(256), 0, st, spec, spec_in_stride, N, plan.start,
-                       plan.bincount, part, nblocks, n0_partials(N));
-  hipLaunchKernelGGL(kh_n0_final, dim3(ninputs), dim3(N0_FT), 0, st, part, energy_part, ingest_chunks(L), L, N, samprate,
+  N0Pass1Args z;
+  int const valid = n0_pass1_args(&z, spec, spec_in_stride, N, plan, part, nblocks, ninputs);
+  if (valid && !pass1_done)
+    hipLaunchKernelGGL(kh_n0_pass1, dim3(N0_GX * nblocks * ninputs), dim3(256), 0, st, z);
+  hipLaunchKernelGGL(kh_n0_final, dim3(ninputs), dim3(N0_FT), 0, st, part, energy_part, echunks, L, N, samprate,
                      valid, have_n0, n0_state, status, nblocks);
   return KH_HIP(hipGetLastError()) ? 0 : -1;
 }

@@ -10,6 +10,7 @@
 #include "kh_fft.cuh"
 #include "kh_regfft.cuh"
 #include "kh_fm.cuh"
+#include "../../include/ka9q_hip.h"
 #include <cstdlib>
 
 namespace kh {
@@ -111,30 +112,178 @@ __device__ __forceinline__ float2 big_tw(BigTwiddle const &bt, unsigned idx) { /
   return cmul(bt.coarse[idx >> 10], bt.fine[idx & 1023]);
 }
 
+
+// ---- fused ingest (radio.c:136-178,188,197 + filter.c:230): the column pass can take its input straight from the
+// raw ring: wire format -> float x gain (no NCO: a launch with an active oscillator goes through kh_ingest), the IF
+// power partial sums of the new samples, and the overlap-save history of the next launch.
+__device__ __forceinline__ float u2f(unsigned u) { return __uint_as_float(u); }
+template <int PT>
+struct RawFmt;
+template <>
+struct RawFmt<KH_PT_CF32> {
+  static constexpr int BPS = 8;
+  static __device__ __forceinline__ kh_u32x2 fetch(__amdgpu_buffer_rsrc_t r, int voff, int soff) {
+    return __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, 0);
+  }
+  static __device__ __forceinline__ float2 decode(kh_u32x2 w, float g) { return make_float2(g * u2f(w.x), g * u2f(w.y)); }
+};
+template <>
+struct RawFmt<KH_PT_IQ16LE> { // radio.c:159-167
+  static constexpr int BPS = 4;
+  static __device__ __forceinline__ kh_u32x2 fetch(__amdgpu_buffer_rsrc_t r, int voff, int soff) {
+    kh_u32x2 w;
+    w.x = __builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, 0);
+    w.y = 0;
+    return w;
+  }
+  static __device__ __forceinline__ float2 decode(kh_u32x2 w, float g) {
+    float const gain = (1.f / 32767.f) * g;
+    return make_float2(gain * (short)(w.x & 0xffff), gain * (short)(w.x >> 16));
+  }
+};
+template <>
+struct RawFmt<KH_PT_PCM16BE> { // radio.c:148-157
+  static constexpr int BPS = 4;
+  static __device__ __forceinline__ kh_u32x2 fetch(__amdgpu_buffer_rsrc_t r, int voff, int soff) {
+    return RawFmt<KH_PT_IQ16LE>::fetch(r, voff, soff);
+  }
+  static __device__ __forceinline__ float2 decode(kh_u32x2 w, float g) {
+    float const gain = (1.f / 32767.f) * g;
+    unsigned const b0 = w.x & 0xff, b1 = (w.x >> 8) & 0xff, b2 = (w.x >> 16) & 0xff, b3 = w.x >> 24;
+    return make_float2(gain * (short)((b0 << 8) | b1), gain * (short)((b2 << 8) | b3));
+  }
+};
+template <>
+struct RawFmt<KH_PT_IQ8> { // radio.c:169-176
+  static constexpr int BPS = 2;
+  static __device__ __forceinline__ kh_u32x2 fetch(__amdgpu_buffer_rsrc_t r, int voff, int soff) {
+    kh_u32x2 w;
+    w.x = __builtin_amdgcn_raw_buffer_load_b16(r, voff, soff, 0);
+    w.y = 0;
+    return w;
+  }
+  static __device__ __forceinline__ float2 decode(kh_u32x2 w, float g) {
+    float const gain = (1.f / 127.f) * g;
+    return make_float2(gain * (signed char)(w.x & 0xff), gain * (signed char)((w.x >> 8) & 0xff));
+  }
+};
+template <>
+struct RawFmt<KH_PT_IQ12> { // radio.c:138-146
+  static constexpr int BPS = 3;
+  static __device__ __forceinline__ kh_u32x2 fetch(__amdgpu_buffer_rsrc_t r, int voff, int soff) {
+    kh_u32x2 w;
+    unsigned const d0 = __builtin_amdgcn_raw_buffer_load_b8(r, voff, soff, 0);
+    unsigned const d1 = __builtin_amdgcn_raw_buffer_load_b8(r, voff + 1, soff, 0);
+    unsigned const d2 = __builtin_amdgcn_raw_buffer_load_b8(r, voff + 2, soff, 0);
+    w.x = d0 | (d1 << 8) | (d2 << 16);
+    w.y = 0;
+    return w;
+  }
+  static __device__ __forceinline__ float2 decode(kh_u32x2 w, float g) {
+    float const gain = (1.f / 32767.f) * g;
+    int const d0 = w.x & 0xff, d1 = (w.x >> 8) & 0xff, d2 = (w.x >> 16) & 0xff;
+    return make_float2(gain * (short)(((d0 << 8) | d1) & 0xfff0), gain * (short)(((d1 << 8) | d2) << 4));
+  }
+};
+
+struct ColsIngest {
+  const unsigned char *raw;   // raw ring, input i at raw + i*raw_stride
+  size_t raw_stride;
+  unsigned raw_bytes;         // bytes of one input's ring
+  int payload;                // enum kh_payload
+  const float2 *hist_in;      // M-1 mixed samples that precede this launch, input i at hist_in + i*hist_stride
+  float2 *hist_out;           // the last M-1 samples of this launch go here (filter.c:230)
+  size_t hist_stride;
+  const IngestDesc *desc;     // gain_factor (the oscillators are inactive on this path)
+  float *energy_part;         // IF power partial sums: [(i*nblocks + b) * ntiles + tile]
+  int M1;                     // M-1
+};
+
+// element (row0 + k*rstep)*N2 + col of block b's window, k < CNT, as samples: window element n is launch-relative
+// sample s = b*L - M1 + n; s < 0 lies in the history.
+template <int PT, int CNT>
+__device__ __forceinline__ void ingest_tile(float2 (&v)[CNT], ColsIngest const &ing, int i, int s_lane, int rstep_elems,
+                                            float gain) {
+  using F = RawFmt<PT>;
+  constexpr int OOB = 0x7ffffff0; // beyond any ring: the buffer load returns zero without touching memory
+  __amdgpu_buffer_rsrc_t const rr = make_rsrc(ing.raw + (size_t)i * ing.raw_stride, ing.raw_bytes);
+  if (__builtin_amdgcn_ballot_w64(s_lane < 0) == 0) { // wave-uniform
+    // every element of the wave is a new sample: one per-lane offset, the row offset travels in an SGPR
+    kh_u32x2 w[CNT];
+#pragma unroll
+    for (int k = 0; k < CNT; k++) w[k] = F::fetch(rr, s_lane * F::BPS, k * rstep_elems * F::BPS);
+#pragma unroll
+    for (int k = 0; k < CNT; k++) v[k] = F::decode(w[k], gain);
+  } else { // the window reaches back into the history (block 0 of a launch, unless L < M-1)
+    __amdgpu_buffer_rsrc_t const rh = make_rsrc(ing.hist_in + (size_t)i * ing.hist_stride, (unsigned)ing.M1 * 8u);
+#pragma unroll
+    for (int k = 0; k < CNT; k++) {
+      int const s = s_lane + k * rstep_elems;
+      kh_u32x2 const h = __builtin_amdgcn_raw_buffer_load_b64(rh, s < 0 ? (ing.M1 + s) * 8 : OOB, 0, 0);
+      kh_u32x2 const w = F::fetch(rr, s >= 0 ? s * F::BPS : OOB, 0);
+      float2 const x = F::decode(w, gain);
+      v[k] = s < 0 ? make_float2(u2f(h.x), u2f(h.y)) : x;
+    }
+  }
+}
+
 constexpr int TILE_W = 16;
 
-template <int RA, int RB, int NT>
+template <int RA, int RB, int NT, bool INGEST>
 __global__ __launch_bounds__(NT, 4) void kh_fft_cols(const float2 *__restrict__ time, size_t in_stride,
                                                   float2 *__restrict__ tmp, size_t spec_in_stride, int N2, int L,
-                                                  const float2 *__restrict__ tw, BigTwiddle bt) {
+                                                  const float2 *__restrict__ tw, BigTwiddle bt, ColsIngest ing) {
   constexpr int W = TILE_W, R = RA * RB;
   constexpr int I1 = W * RB / NT; // RA-point transforms per lane
   constexpr int I2 = W * RA / NT; // RB-point transforms per lane
   static_assert(I1 * NT == W * RB && I2 * NT == W * RA, "tile must divide evenly over the workgroup");
   constexpr int CS = RB * W + 16; // pitch of c: an odd multiple of 16 floats, so two c's in a 32-lane group differ in bank
   __shared__ float ex[RA * CS];
+  __shared__ float red[NT / 64];
   int const tid = threadIdx.x;
   int const tile = blockIdx.x, b = blockIdx.y, i = blockIdx.z;
   unsigned const tile_bytes = (unsigned)R * (unsigned)N2 * 8u; // the block's N points (8 MiB at most)
-  __amdgpu_buffer_rsrc_t const rin = make_rsrc(time + i * in_stride + (size_t)b * L + tile * W, tile_bytes);
   int const row_bytes = N2 * 8;
   float2 v[I1][RA];
-  {
+  if constexpr (!INGEST) {
+    __amdgpu_buffer_rsrc_t const rin = make_rsrc(time + i * in_stride + (size_t)b * L + tile * W, tile_bytes);
     int const voff = (tid / W) * row_bytes + (tid % W) * 8; // item u: NT/W rows further down
 #pragma unroll
     for (int u = 0; u < I1; u++)
 #pragma unroll
       for (int a = 0; a < RA; a++) v[u][a] = buf_load2(rin, voff, (RB * a + u * (NT / W)) * row_bytes);
+  } else {
+    // window element n = row*N2 + col is launch-relative sample b*L - M1 + n; item (u, a) is row (tid/W) + u*(NT/W) + RB*a
+    float const gain = ing.desc[i].gain_factor;
+    int const n_lane = (tid / W) * N2 + tile * W + (tid % W);
+    int const s_lane = b * L - ing.M1 + n_lane;
+#pragma unroll
+    for (int u = 0; u < I1; u++) {
+      int const su = s_lane + u * (NT / W) * N2;
+      switch (ing.payload) {
+      case KH_PT_IQ16LE: ingest_tile<KH_PT_IQ16LE, RA>(v[u], ing, i, su, RB * N2, gain); break;
+      case KH_PT_PCM16BE: ingest_tile<KH_PT_PCM16BE, RA>(v[u], ing, i, su, RB * N2, gain); break;
+      case KH_PT_IQ8: ingest_tile<KH_PT_IQ8, RA>(v[u], ing, i, su, RB * N2, gain); break;
+      case KH_PT_IQ12: ingest_tile<KH_PT_IQ12, RA>(v[u], ing, i, su, RB * N2, gain); break;
+      default: ingest_tile<KH_PT_CF32, RA>(v[u], ing, i, su, RB * N2, gain); break;
+      }
+    }
+    // IF power of the block's new samples (radio.c:188,197: n >= M-1) and the next launch's history (filter.c:230:
+    // the last M-1 points of the launch = window elements n >= L of its last block)
+    float e = 0.f;
+    bool const last = b == (int)gridDim.y - 1;
+    float2 *ho = ing.hist_out + (size_t)i * ing.hist_stride;
+#pragma unroll
+    for (int u = 0; u < I1; u++)
+#pragma unroll
+      for (int a = 0; a < RA; a++) {
+        int const n = n_lane + (u * (NT / W) + RB * a) * N2;
+        float2 const x = v[u][a];
+        if (n >= ing.M1) e += x.x * x.x + x.y * x.y;
+        if (last && n >= L) ho[n - L] = x;
+      }
+    e = block_sum<NT>(e, red);
+    if (tid == 0) ing.energy_part[((size_t)i * gridDim.y + b) * gridDim.x + tile] = e;
   }
 #pragma unroll
   for (int u = 0; u < I1; u++) {
@@ -293,12 +442,20 @@ static int launch_small(hipStream_t st, const void *time, size_t in_stride, int 
 
 template <int RA, int RB, int NT>
 static int launch_cols(hipStream_t st, const float2 *time, size_t in_stride, float2 *tmp, size_t spec_in_stride, int N2,
-                       int L, int nblocks, int ninputs) {
+                       int L, int nblocks, int ninputs, const FftIngest *fi) {
   const float2 *tw = twiddle_table(RA * RB);
   BigTwiddle bt = big_twiddle(RA * RB * N2);
   if (!tw || !bt.fine) return -1;
-  hipLaunchKernelGGL((kh_fft_cols<RA, RB, NT>), dim3(N2 / TILE_W, nblocks, ninputs), dim3(NT), 0, st, time, in_stride,
-                     tmp, spec_in_stride, N2, L, tw, bt);
+  dim3 const grid(N2 / TILE_W, nblocks, ninputs);
+  if (fi) {
+    ColsIngest const ing{static_cast<const unsigned char *>(fi->raw), fi->raw_stride_bytes, fi->raw_bytes, fi->payload,
+                         fi->hist_in, fi->hist_out, fi->hist_stride, fi->desc, fi->energy_part, fi->M - 1};
+    hipLaunchKernelGGL((kh_fft_cols<RA, RB, NT, true>), grid, dim3(NT), 0, st, time, in_stride, tmp, spec_in_stride, N2, L,
+                       tw, bt, ing);
+  } else {
+    hipLaunchKernelGGL((kh_fft_cols<RA, RB, NT, false>), grid, dim3(NT), 0, st, time, in_stride, tmp, spec_in_stride, N2,
+                       L, tw, bt, ColsIngest{});
+  }
   return KH_HIP(hipGetLastError()) ? 0 : -1;
 }
 template <int RA, int RB, int NT>
@@ -323,14 +480,24 @@ int n0_partials(int N) { // first-pass partial sums the forward transform leaves
   return (1 << ((e + 1) / 2)) / TILE_W;
 }
 
+int fused_ingest_tiles(int N) { // IF power partial sums the fused column pass leaves per (input, block); 0: no fused pass
+  if (N <= KH_MAX_SMALL_N) return 0;
+  return (1 << (ilog2((unsigned)N) / 2)) / TILE_W;
+}
+
 int launch_forward_fft(hipStream_t st, const void *time, size_t in_stride, int real_input, float2 *spec, float2 *tmp,
-                       size_t spec_in_stride, int N, int L, int nblocks, int ninputs, hipEvent_t mid_event, N0Fuse n0) {
+                       size_t spec_in_stride, int N, int L, int nblocks, int ninputs, hipEvent_t mid_event, N0Fuse n0,
+                       const FftIngest *fi) {
   if (N < 256 || (N & (N - 1)) || N > (1 << 20)) {
     set_error("forward FFT size %d unsupported (power of two in [256, 2^20] required)", N);
     return -1;
   }
   if (nblocks <= 0 || ninputs <= 0) return 0;
   if (N <= KH_MAX_SMALL_N) {
+    if (fi) {
+      set_error("fused ingest needs N > %d", KH_MAX_SMALL_N);
+      return -1;
+    }
     int rc = -1;
     switch (N) {
     case 256: rc = launch_small<256>(st, time, in_stride, real_input, spec, spec_in_stride, L, nblocks, ninputs, n0); break;
@@ -352,10 +519,10 @@ int launch_forward_fft(hipStream_t st, const void *time, size_t in_stride, int r
   const float2 *t = static_cast<const float2 *>(time);
   int rc = -1;
   switch (N1) {
-  case 128: rc = launch_cols<8, 16, 128>(st, t, in_stride, tmp, spec_in_stride, N2, L, nblocks, ninputs); break;
-  case 256: rc = launch_cols<16, 16, 256>(st, t, in_stride, tmp, spec_in_stride, N2, L, nblocks, ninputs); break;
-  case 512: rc = launch_cols<16, 32, 256>(st, t, in_stride, tmp, spec_in_stride, N2, L, nblocks, ninputs); break;
-  case 1024: rc = launch_cols<32, 32, 512>(st, t, in_stride, tmp, spec_in_stride, N2, L, nblocks, ninputs); break;
+  case 128: rc = launch_cols<8, 16, 128>(st, t, in_stride, tmp, spec_in_stride, N2, L, nblocks, ninputs, fi); break;
+  case 256: rc = launch_cols<16, 16, 256>(st, t, in_stride, tmp, spec_in_stride, N2, L, nblocks, ninputs, fi); break;
+  case 512: rc = launch_cols<16, 32, 256>(st, t, in_stride, tmp, spec_in_stride, N2, L, nblocks, ninputs, fi); break;
+  case 1024: rc = launch_cols<32, 32, 512>(st, t, in_stride, tmp, spec_in_stride, N2, L, nblocks, ninputs, fi); break;
   }
   if (rc) return rc;
   if (mid_event) hipEventRecord(mid_event, st);
@@ -502,16 +669,19 @@ static int launch_fo(hipStream_t st, const float2 *spec, size_t spec_in_stride, 
 
 int launch_filter_output(hipStream_t st, const float2 *spec, size_t spec_in_stride, int N, int in_real,
                          const ChanDesc *chans, const float2 *response, int ND, int olen, void *out, size_t out_stride,
-                         int nblocks, int nchan, FmFront const &fm, int complex_out) {
+                         int nblocks, int nchan, FmFront const &fm, int complex_out, const N0Pass1Args *n0, int *n0_taken) {
+  if (n0_taken) *n0_taken = 0;
   if (nblocks <= 0 || nchan <= 0) return 0;
   if (olen > ND || ND > N) {
     set_error("filter output: olen %d > N_dec %d or N_dec > N %d", olen, ND, N);
     return -1;
   }
   static int const wave_env = getenv("KA9Q_HIP_CHAN_WAVE") ? atoi(getenv("KA9Q_HIP_CHAN_WAVE")) : 1; // A/B switch
-  if (wave_env && complex_out && !in_real && chan_wave_supported(ND, olen))
+  if (wave_env && complex_out && !in_real && chan_wave_supported(ND, olen)) {
+    if (n0_taken) *n0_taken = n0 != nullptr;
     return launch_chan_wave(st, spec, spec_in_stride, N, chans, response, ND, olen, static_cast<float2 *>(out), out_stride,
-                            nblocks, nchan, fm);
+                            nblocks, nchan, fm, n0);
+  }
 #define FO(n) \
   case n: return launch_fo<n>(st, spec, spec_in_stride, N, in_real, chans, response, olen, out, out_stride, nblocks, nchan, fm)
   switch (ND) {

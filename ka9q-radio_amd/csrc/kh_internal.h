@@ -8,6 +8,8 @@
 
 namespace kh {
 
+struct N0Pass1Args; // kh_n0.cuh
+
 // ---------------------------------------------------------------- errors
 void set_error(const char *fmt, ...);
 bool check_hip(hipError_t e, const char *what);
@@ -116,19 +118,40 @@ struct N0Fuse {
   int start, bincount; // radio.c:440-447: bins (start + n) mod N, n < bincount
 };
 int n0_partials(int N);
+// fi != nullptr (N > KH_MAX_SMALL_N only): the first pass reads the raw ring itself instead of `time` -- wire format
+// -> float x gain_factor (radio.c:136-178; no oscillator: the caller uses launch_ingest when one is active), leaves
+// fused_ingest_tiles(N) IF-power partial sums per (input, block) and stores the last M-1 samples of the launch in
+// hist_out (filter.c:230).  hist_in holds the M-1 samples that precede the launch.
+struct FftIngest {
+  const void *raw;
+  size_t raw_stride_bytes;
+  unsigned raw_bytes;
+  int payload;
+  const float2 *hist_in;
+  float2 *hist_out;
+  size_t hist_stride;
+  const IngestDesc *desc;
+  float *energy_part;
+  int M;
+};
+int fused_ingest_tiles(int N);
 int launch_forward_fft(hipStream_t st, const void *time, size_t in_stride, int real_input, float2 *spec, float2 *tmp,
-                       size_t spec_in_stride, int N, int L, int nblocks, int ninputs, hipEvent_t mid_event, N0Fuse n0);
+                       size_t spec_in_stride, int N, int L, int nblocks, int ninputs, hipEvent_t mid_event, N0Fuse n0,
+                       const FftIngest *fi = nullptr);
 // bin-select x response x inverse transform.  out: cf32 (or f32 when out_type REAL) at
 // out + ch*out_stride + b*olen.
 // complex_out: 1 if no channel has out_type REAL (known on the host): shapes that have one then take the
 // wave-resident kernel of kh_chan_kernels.hip.
+// n0 (may be null): compute_n0's second iteration rides along in the same launch when the wave-resident kernel is
+// taken; *n0_taken says whether it did.
 int launch_filter_output(hipStream_t st, const float2 *spec, size_t spec_in_stride, int N, int in_real,
                          const ChanDesc *chans, const float2 *response, int ND, int olen, void *out, size_t out_stride,
-                         int nblocks, int nchan, FmFront const &fm, int complex_out);
+                         int nblocks, int nchan, FmFront const &fm, int complex_out, const N0Pass1Args *n0 = nullptr,
+                         int *n0_taken = nullptr);
 int chan_wave_supported(int ND, int olen);
 int launch_chan_wave(hipStream_t st, const float2 *spec, size_t spec_in_stride, int N, const ChanDesc *chans,
                      const float2 *response, int ND, int olen, float2 *out, size_t out_stride, int nblocks, int nchan,
-                     FmFront const &fm);
+                     FmFront const &fm, const N0Pass1Args *n0);
 // wire format -> cf32 * gain * Doppler * LO2 and per-block energy (radio.c:136-191)
 // energy_part: ingest_chunks(L) floats per (input, block), summed by launch_n0
 int ingest_chunks(int L);
@@ -143,9 +166,14 @@ struct N0Plan {
   int valid, start, bincount;
 };
 N0Plan n0_plan(int N, int samprate, float low, float high);
+// fills *z with the second iteration's arguments; 0 if there is nothing to do (compute_n0 off, empty bin range)
+int n0_pass1_args(N0Pass1Args *z, const float2 *spec, size_t spec_in_stride, int N, N0Plan plan, float *part, int nblocks,
+                  int ninputs);
+// pass1_done: the second iteration has already run (inside launch_chan_wave's kernel)
 int launch_n0(hipStream_t st, const float2 *spec, size_t spec_in_stride, int N, int samprate, N0Plan plan,
-              const float *energy_part, int L, float *n0_state, float *part /*n0_part_floats() per (input,block)*/,
-              void *input_status, int nblocks, int ninputs);
+              const float *energy_part, int echunks /*partial sums per (input, block)*/, int L, float *n0_state,
+              float *part /*n0_part_floats() per (input,block)*/, void *input_status, int nblocks, int ninputs,
+              int pass1_done = 0);
 // demodulators + scaleclip
 int launch_demod(hipStream_t st, float2 *baseband, size_t bb_stride, int olen, int nblocks, int nchan,
                  const DemodDesc *desc, DemodState *state, float *audio, int16_t *pcm, size_t pcm_stride,

@@ -1,0 +1,78 @@
+// kh_n0.cuh -- compute_n0's second iteration (radio.c:451-462) as a device function, so that it can be a kernel of
+// its own (kh_n0_pass1) or share a launch with the channel wavefronts (kh_back_a, kh_chan_kernels.hip).
+#pragma once
+#include <hip/hip_runtime.h>
+#include "kh_internal.h"
+
+namespace kh {
+
+constexpr int N0_GX = 64; // workgroups (slices) per (input, block)
+
+struct N0Pass1Args {
+  const float2 *spec;
+  size_t spec_in_stride;
+  int N, start, bincount; // radio.c:440-447: bins (start + n) mod N, n < bincount
+  float *part;            // layout below
+  int nblocks, ninputs, npart0, gx;
+};
+
+__device__ __forceinline__ float n0_wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+// part layout: [0, PT*N0_SLOTS) first-pass sums (left by the forward transform); then PT*N0_GX pairs {sum1, count1}
+// (PT = ninputs*nblocks).  wg = slice + N0_GX*(block + nblocks*input); 256 threads; `sh` holds >= 8 floats.
+// algorithmic bytes: 8*bincount per (input, block)
+__device__ __forceinline__ void n0_pass1_body(N0Pass1Args const &Z, int wg, float *sh) {
+  float *ps = sh, *pc = sh + 4;
+  int const tid = threadIdx.x;
+  int const slice = wg % Z.gx, b = (wg / Z.gx) % Z.nblocks, i = wg / (Z.gx * Z.nblocks);
+  const float2 *fd = Z.spec + (size_t)i * Z.spec_in_stride + (size_t)b * Z.N;
+  size_t const pt = (size_t)i * Z.nblocks + b;
+  const float *p0 = Z.part + pt * N0_SLOTS;
+  float *p1 = Z.part + (size_t)Z.ninputs * Z.nblocks * N0_SLOTS + pt * (2 * N0_GX);
+  // radio.c:456,461: twice the mean of iteration 0 (npart0 <= 64 partials, added in a fixed order)
+  float t = tid < Z.npart0 ? p0[tid] : 0.f;
+  t = n0_wave_sum(t);
+  if ((tid & 63) == 0) ps[tid >> 6] = t; // all partials sit in wave 0
+  __syncthreads();
+  float const th = (ps[0] / Z.bincount) * 2;
+  __syncthreads();
+  float s = 0.f, c = 0.f;
+  // eight loads in flight per lane: when this shares a launch with the channel wavefronts their LDS footprint caps
+  // the workgroups per CU, and one load at a time would leave the memory system idle
+  int const stride = Z.gx * 256;
+  for (int n0 = slice * 256 + tid; n0 < Z.bincount; n0 += 8 * stride) {
+    float2 x[8];
+#pragma unroll
+    for (int u = 0; u < 8; u++) {
+      int const n = n0 + u * stride;
+      int in = Z.start + n; // radio.c:440-446
+      if (in >= Z.N) in -= Z.N;
+      x[u] = n < Z.bincount ? fd[in] : make_float2(INFINITY, 0.f);
+    }
+#pragma unroll
+    for (int u = 0; u < 8; u++) {
+      float const p = x[u].x * x[u].x + x[u].y * x[u].y;
+      if (p < th) {
+        s += p;
+        c += 1.f;
+      }
+    }
+  }
+  s = n0_wave_sum(s);
+  c = n0_wave_sum(c);
+  if ((tid & 63) == 0) {
+    ps[tid >> 6] = s;
+    pc[tid >> 6] = c;
+  }
+  __syncthreads();
+  if (tid == 0) {
+    p1[2 * slice] = ps[0] + ps[1] + ps[2] + ps[3];
+    p1[2 * slice + 1] = pc[0] + pc[1] + pc[2] + pc[3];
+  }
+}
+
+} // namespace kh

@@ -127,6 +127,50 @@ def test_lo2_and_doppler_sweep_phase_continuity_across_launches(hip):
     bank.close()
 
 
+
+# ------------------------------------------------------------------ large transforms: ingest fused into the FFT
+@pytest.mark.parametrize("payload", [orc.IQ_PT, orc.PCM_STEREO_PT, orc.IQ_PT8, orc.IQ_PT12, 0])
+@pytest.mark.parametrize("shape", [(8192, 8193, 16, 2), (4096, 12289, 16, 1)])
+def test_fused_ingest_large_transform(hip, payload, shape):
+    """N = 16384 goes through the four-step transform whose first pass reads the raw ring itself (convert, gain, IF
+    power, overlap-save history): three launches so that the history crosses launches -- with L < M-1 and one block
+    per launch the history even feeds the next history -- then a launch with LO2 set, which takes the unfused
+    kh_ingest path and must continue from the same history."""
+    Lb, Mb, Db, T = shape
+    rng = np.random.default_rng(payload + Lb)
+    calls = 4
+    # (the carrier sits inside the passband: against an out-of-band one the output would be float round-off)
+    x = (synth.noise(calls * T * Lb, 0.05, 11) + synth.fm_carrier(0, calls * T * Lb, FS, 1.5e3, 0.3, 700.0, 1000.0)).astype(np.complex64)
+    raw = x if payload == 0 else _raw(payload, x, rng)
+    per = raw.size // (calls * T)
+    bank = hip.Bank(Lb, Mb, Db, 1, 1, T, FS, payload=payload)
+    pipe = pipeline.Pipeline(Lb, Mb, Db, FS, payload=payload)
+    bank.set_gain(0, 0.75)
+    pipe.fins[0].gain = 0.75
+    bank.set_channel(0, low=-4000.0, high=4000.0)
+    pipe.add_channel(low=-4000.0, high=4000.0)
+    olen = Lb // Db
+    for call in range(calls):
+        if call == 3:
+            bank.set_second_lo(0, -1000.0 / FS)
+            orc.lib().orc_set_osc(C.addressof(pipe.fins[0].lo2), -1000.0 / FS, 0.0)
+        seg = raw[call * T * per:(call + 1) * T * per]
+        bank.write_input(0, seg, count=T * Lb)
+        bank.execute(T)
+        ist = bank.input_status(0, T)
+        bb = bank.baseband(0, T)
+        for b in range(T):
+            outs, istat = pipe.run_block([seg[b * per:(b + 1) * per]])
+            assert rel_rms(bank.spectrum(0, b), pipe.spectrum(0)) < 1e-5, (call, b)
+            # status-scalar bar (1e-4): the reference adds L floats one by one, the GPU in a tree
+            assert abs(ist[b]["if_power"] - istat[0][0]) <= 1e-4 * istat[0][0], (call, b)
+            y, want = bb[b * olen:(b + 1) * olen], outs[0][0]
+            if (call * T + b) * Lb >= Mb - 1:
+                assert rel_rms(y, want) < 1e-5, (call, b)
+            else:  # filter still filling: the output is pre-ringing far below the carrier (0.3 * 0.75), bar relative to that
+                assert np.linalg.norm(y - want) / np.sqrt(olen) < 1e-5 * 0.225, (call, b)
+    bank.close()
+
 # ------------------------------------------------------------------ decimate.c
 def _f8_states(n):
     arr = (hip_Hb15 * n)()
