@@ -14,6 +14,7 @@
 // channel; the per-sample recurrences of linear.c / am.c (PLL, hang AGC, DC tracker) are serial by
 // definition and run one LANE per channel, 64 channels in lock-step per wavefront.
 #include "kh_internal.h"
+#include <cstdlib>
 #include "kh_fft.cuh"
 #include "kh_fm.cuh"
 #include "kh_ingest.cuh"
@@ -421,6 +422,260 @@ __global__ __launch_bounds__(FMB_NT) void kh_fm_finish(int olen, int nblocks, co
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// The same step with ONE wavefront per (channel, block): lane l owns samples K l .. K l + K - 1 (K =
+// ceil(olen / 64)), the earlier blocks' carries are folded by one lane each and summed across the wave, the
+// peak-deviation replay uses a wave-wide prefix maximum and a lane-by-lane pass; no LDS.  Four such waves share a workgroup; they never
+// wait for each other.  This is the form the bank uses (kh_fm_finish above remains for olen > 1024 or more than 64 blocks per launch).
+struct FinishArgs {
+  int olen, nblocks;
+  const DemodDesc *descs;
+  DemodState *states;
+  int par;
+  const FmBlockStat *fmstat;
+  int stat_stride;
+  const FmWork *work;
+  size_t work_stride;
+  const double *carry;
+  const double *decay_pow;
+  float *audio;
+  int16_t *pcm;
+  size_t pcm_stride;
+  int big_endian;
+  kh_status *status;
+  int status_stride;
+  const int *list;
+  int n_fm;
+};
+
+__device__ __forceinline__ double wave_sum_f64(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+template <int K>
+__device__ __forceinline__ void fm_finish_wave(FinishArgs const &F, int q, int lane) {
+  int const olen = F.olen;
+  int const ch = F.list[q % F.n_fm], b = q / F.n_fm;
+  const DemodDesc *dd = F.descs + ch;
+  DemodState *st = F.states + ch;
+  const FmBlockStat *fs = F.fmstat + (size_t)ch * F.stat_stride;
+  const double *cb = F.carry + (size_t)ch * F.stat_stride;
+  int const par = F.par;
+  int const flat = dd->flat;
+  float const dsamprate = dd->dsamprate, gain = dd->fm_gain;
+  int const so_in = st->fm_squelch_open[par];
+  float2 const state_in = st->fm_state[par];
+  float const lastaudio_in = st->fm_lastaudio[par];
+  double const Ablk = F.decay_pow[olen];
+  // this lane's samples: issued before anything that depends on the statistics
+  const FmWork *wi = F.work + (size_t)ch * F.work_stride + (size_t)b * olen;
+  int const n0 = K * lane;
+  FmWork w[K];
+  double dp[K];
+  if ((K % 2) == 0 && (olen % 2) == 0) { // 16-byte loads
+#pragma unroll
+    for (int j = 0; j < K; j += 2) {
+      int const n = n0 + j;
+      float4 const v = n < olen ? *reinterpret_cast<const float4 *>(wi + n) : make_float4(0.f, 0.f, 0.f, 0.f);
+      double2 const d = n < olen ? *reinterpret_cast<const double2 *>(F.decay_pow + n) : make_double2(0.0, 0.0);
+      w[j] = FmWork{v.x, v.y};
+      w[j + 1] = FmWork{v.z, v.w};
+      dp[j] = d.x;
+      dp[j + 1] = d.y;
+    }
+  } else {
+#pragma unroll
+    for (int j = 0; j < K; j++) {
+      int const n = n0 + j;
+      w[j] = n < olen ? wi[n] : FmWork{0.f, 0.f};
+      dp[j] = n < olen ? F.decay_pow[n] : 0.0;
+    }
+  }
+  // lane j holds the statistics of block j (nblocks <= 64): everything that looks at another block is a shuffle
+  bool const have = lane < F.nblocks;
+  FmBlockStat sj = have ? fs[lane] : FmBlockStat{0.f, 1.f, 0.f, 0.f, make_float2(0.f, 0.f), make_float2(0.f, 0.f)};
+  double const cj = have ? cb[lane] : 0.0;
+  // fm.c:73-78 in closed form (see fm_counter_after): counter after block j
+  int cnt_j = sj.snr > 4.f ? 1 : (lane == 0 ? (so_in - 1 > 0 ? so_in - 1 : 0) : 0);
+  int cnt_prev = __shfl_up(cnt_j, 1, 64);
+  if (lane == 0) cnt_prev = so_in;
+  int const open_j = sj.snr > 4.f || cnt_prev > 0;
+  int open_prev = __shfl_up(open_j, 1, 64);
+  float2 prev = make_float2(__shfl_up(sj.last.x, 1, 64), __shfl_up(sj.last.y, 1, 64));
+  if (!open_prev) prev = make_float2(0.f, 0.f); // fm.c:123
+  if (lane == 0) prev = state_in;
+  // sample 0 of block j (fm.c:86-93,110): p = y_j[0] conj(previous sample)
+  float2 const p0 = cmulc(sj.first, prev);
+  float const ang0_j = atan2f(p0.y, p0.x);
+  float amp0 = hypotf(p0.x, p0.y) / sj.variance;
+  if (amp0 > 1) amp0 = 1;
+  double const x0_j = (double)ang0_j * .114 * (double)gain * (double)amp0;
+  int const open = __shfl(open_j, b, 64), so = __shfl(cnt_j, b, 64);
+  // lastaudio on entry to this block (fm.c:110-111,130): c_b = A^b c_0 + sum_{j<b} A^(b-1-j) E_j, E_j = carry_j + A x0_j for
+  // a demodulated block (its own sample 0 enters ahead of the zero-carry run), 0 for a closed one
+  double acc = (double)lastaudio_in;
+  if (!flat) {
+    double v = 0.0;
+    int m = 0; // blocks to decay over
+    if (lane < b) {
+      m = b - 1 - lane;
+      if (open_j) v = cj + Ablk * x0_j;
+    } else if (lane == b) { // the carried lastaudio rides in the first lane that has no block to fold
+      m = b;
+      v = (double)lastaudio_in;
+    }
+    double pw = 1.0, qq = Ablk;
+    while (m > 0) {
+      if (m & 1) pw *= qq;
+      qq *= qq;
+      m >>= 1;
+    }
+    acc = wave_sum_f64(v * pw);
+  }
+  float const ang0 = open ? __shfl(ang0_j, b, 64) : 0.f;
+  double const x0 = open ? __shfl(x0_j, b, 64) : 0.0;
+  double const c_in = acc;                   // lastaudio before sample 0
+  double const c0 = flat ? acc : acc + x0;   // and after its increment
+  float const sb_bb = __shfl(sj.bb_power, b, 64), sb_snr = __shfl(sj.snr, b, 64), sb_angsum = __shfl(sj.angsum, b, 64);
+  float2 const sb_last = make_float2(__shfl(sj.last.x, b, 64), __shfl(sj.last.y, b, 64));
+  double const cb_b = __shfl(cj, b, 64);
+
+  // ---- fm.c:105-111,124-138: audio, scaleclip, output level
+  float ang[K], s1[K], la[K];
+  float lv = 0.f;
+#pragma unroll
+  for (int j = 0; j < K; j++) {
+    int const n = n0 + j;
+    float a = 0.f, s = 0.f;
+    if (open) {
+      a = n ? w[j].ang : ang0;
+      if (flat)
+        s = n ? w[j].s0 : ang0 * gain; // fm.c:105
+      else
+        s = (float)((double)w[j].s0 + c0 * dp[j]);
+    } else {
+      s = flat ? 0.f : (float)(c_in * dp[j]); // fm.c:124-132: the decaying carry alone
+    }
+    if (n >= olen) s = 0.f;
+    ang[j] = a;
+    s1[j] = s;
+    lv += s * s;
+  }
+  { // lastaudio when sample n is processed = previous sample * decay (fm.c:110-111); flat: it never changes
+    float const prev_lane = __shfl_up(s1[K - 1], 1, 64);
+#pragma unroll
+    for (int j = 0; j < K; j++) {
+      float const sp = j ? s1[j - 1] : prev_lane;
+      la[j] = flat ? (float)c_in : (float)((double)sp * FM_DECAY);
+    }
+  }
+  size_t const obase = (size_t)b * olen + n0;
+  int16_t *po = F.pcm + (size_t)ch * F.pcm_stride + obase;
+  float *ao = F.audio ? F.audio + (size_t)ch * F.pcm_stride + obase : nullptr;
+  if ((K % 8) == 0 && (olen % 8) == 0) { // 16-byte stores
+    if (n0 < olen) {
+#pragma unroll
+      for (int j = 0; j < K; j += 8) {
+        unsigned wd[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++)
+          wd[u] = (unsigned)(unsigned short)pcm_word(s1[j + 2 * u], F.big_endian) |
+                  ((unsigned)(unsigned short)pcm_word(s1[j + 2 * u + 1], F.big_endian) << 16);
+        *reinterpret_cast<uint4 *>(po + j) = make_uint4(wd[0], wd[1], wd[2], wd[3]);
+      }
+    }
+  } else {
+#pragma unroll
+    for (int j = 0; j < K; j++)
+      if (n0 + j < olen) po[j] = pcm_word(s1[j], F.big_endian);
+  }
+  if (ao) {
+#pragma unroll
+    for (int j = 0; j < K; j++)
+      if (n0 + j < olen) ao[j] = s1[j];
+  }
+  float const level = wave_sum(lv) / olen; // fm.c:135-138
+
+  // ---- fm.c:97-102, order dependent: pdev_pos is a running maximum; pdev_neg moves to ang_k at the first later
+  // sample that is not a new maximum and whose lastaudio is below the current pdev_neg, then the search goes on
+  // from there with the new value.  Same result as the serial loop, sample for sample.
+  float pdev_pos = 0.f, pdev_neg = 0.f;
+  if (open) {
+    float lmax = -INFINITY;
+#pragma unroll
+    for (int j = 0; j < K; j++)
+      if (n0 + j < olen) lmax = fmaxf(lmax, ang[j]);
+    float inc = lmax; // inclusive prefix maximum over lanes
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      float const p = __shfl_up(inc, o, 64);
+      if (lane >= o) inc = fmaxf(inc, p);
+    }
+    float run = __shfl_up(inc, 1, 64);
+    if (lane == 0) run = -INFINITY;
+    pdev_pos = __shfl(inc, 63, 64);
+    float thr[K]; // lastaudio where fm.c:101 is reached, +inf elsewhere
+#pragma unroll
+    for (int j = 0; j < K; j++) {
+      int const n = n0 + j;
+      bool const up = ang[j] > run; // fm.c:99: ang > pdev_pos
+      thr[j] = (up || n == 0 || n >= olen) ? INFINITY : la[j];
+      if (n < olen) run = fmaxf(run, ang[j]);
+    }
+    pdev_neg = __shfl(ang[0], 0, 64); // fm.c:97-98
+    // fm.c:101-102 is a chain through the block (on a typical signal every other sample moves pdev_neg), replayed
+    // literally: lanes in order, each running its K samples from the value the lane before left (wave-uniform, so
+    // it travels in a scalar register; no memory in the loop)
+    float cur = pdev_neg;
+    for (int l = 0; l < 64; l++) {
+      float c = cur;
+#pragma unroll
+      for (int j = 0; j < K; j++)
+        if (thr[j] < c) c = ang[j];
+      cur = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(c), l));
+    }
+    pdev_neg = cur;
+  }
+  if (lane == 0) {
+    kh_status r;
+    r.bb_power = sb_bb;
+    r.snr = sb_snr;
+    r.foffset = NAN; // fm.c:116,121 leave both untouched while the squelch is closed
+    r.pdeviation = NAN;
+    if (open) {
+      float const avg_f = (sb_angsum + ang0) / olen; // fm.c:96,114
+      r.foffset = (float)((double)(dsamprate * avg_f) * (0.5 * M_1_PI)); // fm.c:116
+      pdev_pos -= avg_f;
+      pdev_neg -= avg_f;
+      r.pdeviation = (float)((double)(dsamprate * fmaxf(pdev_pos, -pdev_neg)) * (0.5 * M_1_PI)); // fm.c:121
+    }
+    r.cphase = 0.f;
+    r.lock_timer = 0.f;
+    r.pll_lock = 0;
+    r.output_level = level;
+    r.agc_gain = NAN;
+    r.squelch_open = so;
+    r.reserved[0] = r.reserved[1] = 0.f;
+    F.status[(size_t)ch * F.status_stride + b] = r;
+    if (b == F.nblocks - 1) { // state carried to the next launch (fm.c:26,32,33)
+      double c = c_in;
+      if (!flat) c = open ? Ablk * c0 + cb_b : Ablk * c_in;
+      // written to the other parity slot: waves of this launch may still be reading the current one
+      st->fm_lastaudio[par ^ 1] = (float)c;
+      st->fm_squelch_open[par ^ 1] = so;
+      st->fm_state[par ^ 1] = open ? sb_last : make_float2(0.f, 0.f);
+    }
+  }
+}
+
+template <int K>
+__global__ __launch_bounds__(256) void kh_fm_finish_w(FinishArgs F, int npairs) {
+  int const q = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (q < npairs) fm_finish_wave<K>(F, q, threadIdx.x & 63);
+}
+
 // ================================================================ oscillator recurrence, osc.c:39-58 (serial users)
 struct DOsc {
   double re, im, sre, sim;
@@ -656,9 +911,22 @@ int launch_demod(hipStream_t st, float2 *baseband, size_t bb_stride, int olen, i
       set_error("FM demodulator: olen %d outside [2, 8192]", olen);
       return -1;
     }
-    hipLaunchKernelGGL(kh_fm_finish, dim3(n_fm, nblocks), dim3(FMB_NT), olen * sizeof(float2), st, olen, nblocks, desc,
-                       state, fm.parity, fm.stat, status_stride, fm.work, bb_stride, fm.carry, fm.decay_pow, audio, pcm,
-                       pcm_stride, pcm_big_endian, stt, status_stride, fm_list);
+    FinishArgs const F{olen, nblocks, desc, state, fm.parity, fm.stat, status_stride, fm.work, bb_stride, fm.carry,
+                       fm.decay_pow, audio, pcm, pcm_stride, pcm_big_endian, stt, status_stride, fm_list, n_fm};
+    int const npairs = n_fm * nblocks;
+    dim3 const grid((npairs + 3) / 4);
+    int const K = (olen + 63) / 64;
+    static int const wave_env = getenv("KA9Q_HIP_FINISH_WAVE") ? atoi(getenv("KA9Q_HIP_FINISH_WAVE")) : 1; // A/B switch
+    if (!wave_env || K > 16 || nblocks > 64) // (the wave form keeps 8 K registers of samples and one block's statistics per lane)
+      hipLaunchKernelGGL(kh_fm_finish, dim3(n_fm, nblocks), dim3(FMB_NT), olen * sizeof(float2), st, olen, nblocks, desc,
+                         state, fm.parity, fm.stat, status_stride, fm.work, bb_stride, fm.carry, fm.decay_pow, audio, pcm,
+                         pcm_stride, pcm_big_endian, stt, status_stride, fm_list);
+    else if (K <= 4)
+      hipLaunchKernelGGL(kh_fm_finish_w<4>, grid, dim3(256), 0, st, F, npairs);
+    else if (K <= 8)
+      hipLaunchKernelGGL(kh_fm_finish_w<8>, grid, dim3(256), 0, st, F, npairs);
+    else
+      hipLaunchKernelGGL(kh_fm_finish_w<16>, grid, dim3(256), 0, st, F, npairs);
   }
   if (n_lin > 0)
     hipLaunchKernelGGL(kh_demod_linear, dim3((n_lin + 63) / 64), dim3(64), 0, st, baseband, bb_stride, olen, nblocks,
