@@ -60,14 +60,17 @@ def make_input_torch(plan, device):
     return x.contiguous()
 
 
-def stage_bytes(bincount):
-    """algorithmic bytes per launch of each stage (DESIGN.md 'Kernels'): what the kernel must read + write."""
+def stage_bytes(bincount, n0_rides):
+    """algorithmic bytes per launch of each stage (DESIGN.md 'Kernels'): what the kernel must read + write.
+    fft1 = kh_fft_cols reading the raw ring itself (8 B/sample cf32, N samples per block window) and writing the
+    column-transformed block; chan = kh_back_a: per (channel, block) N_dec spectrum bins + N_dec response + the FM work
+    record per output sample, plus compute_n0's second iteration (8 B per counted bin) when it rides along."""
     return {
         "ingest": T * L * (8 + 8),
         "fft1": T * 16 * N,
         "fft2": T * 16 * N,
-        "n0": T * 2 * 8 * bincount,
-        "chan": C * T * (8 * ND + 8 * ND + 8 * OLEN),
+        "n0": T * 8 * bincount,
+        "chan": C * T * (8 * ND + 8 * ND + 8 * OLEN) + (T * 8 * bincount if n0_rides else 0),
         "demod": C * T * (8 * OLEN + 2 * OLEN),
         "carry": 2 * 8 * (M - 1),
     }
@@ -175,13 +178,25 @@ def main():
 
     if rank == 0:
         bincount = N - (int((N * 5500.0) / FS) - int((N * -5500.0) / FS))
-        sb = stage_bytes(bincount)
+        # compute_n0's second iteration shares kh_back_a's launch for this shape (kh_bank.cpp enqueue_back)
+        n0_rides = (ND == 1024 and 2 * OLEN == ND and os.environ.get("KA9Q_HIP_RIDE_N0", "1") != "0"
+                    and os.environ.get("KA9Q_HIP_CHAN_WAVE", "1") != "0")
+        sb = stage_bytes(bincount, n0_rides)
         stages = {}
         for name, (ms, n) in st.items():
             if n:
                 avg = ms / n
                 stages[name] = {"ms": round(avg, 5), "GBps": round(sb[name] / (avg * 1e-3) / 1e9, 1) if avg > 0 else None}
         dom = max((k for k in stages if k != "carry"), key=lambda k: stages[k]["ms"])
+        traffic = None  # HBM bytes per launch of that kernel from the committed PMC passes (profiles/, tools/summarize_prof.py)
+        try:
+            prof = json.load(open(os.path.join(ROOT, "profiles", "r01_step3_hbm_traffic.json")))["kernels"]
+            key = {"fft1": "kh_fft_cols", "fft2": "kh_fft_rows", "chan": "kh_back_a", "demod": "kh_fm_finish_w", "n0": "kh_n0_pass1"}.get(dom)
+            hit = [v for k, v in prof.items() if key and key in k]
+            if hit and world == 1 and T == 32:
+                traffic = hit[0]["hbm_bytes_per_launch"]
+        except (OSError, ValueError, KeyError):
+            pass
         dom_ms = stages[dom]["ms"]
         achieved = sb[dom] / (dom_ms * 1e-3) / 1e9
         kernel_name = pyka9q.lib().kh_stage_kernel_name(pyka9q.KH_STAGES.index(dom)).decode()
@@ -208,7 +223,8 @@ def main():
             "pipeline_GBps_algorithmic": round(total_alg / (ms_per_step * 1e-3) / 1e9, 1),
             "stages": stages,
             "roofline": {"bound": "hbm", "kernel": kernel_name, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS,
-                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": None,
+                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic,
+                         "traffic_source": "profiles/r01_step3_hbm_traffic.json (separate rocprofv3 --pmc passes of this command)" if traffic else None,
                          "algorithmic_bytes_per_launch": sb[dom], "avg_launch_ms": dom_ms},
         }
         if not args.no_cpu:

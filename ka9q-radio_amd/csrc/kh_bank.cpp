@@ -759,12 +759,12 @@ int kh_bank_stage_times(kh_bank *b, float ms[KH_STAGE_COUNT], unsigned int launc
 }
 const char *kh_stage_kernel_name(int stage) {
   switch (stage) {
-  case KH_STAGE_INGEST: return "kh_ingest";
-  case KH_STAGE_FFT1: return "kh_fft_pass1|kh_fft_fwd_lds";
-  case KH_STAGE_FFT2: return "kh_fft_pass2";
-  case KH_STAGE_N0: return "kh_n0_pass+kh_n0_final";
-  case KH_STAGE_CHAN: return "kh_filter_out";
-  case KH_STAGE_DEMOD: return "kh_demod_fm|kh_demod_linear|kh_demod_am";
+  case KH_STAGE_INGEST: return "kh_ingest";                   // zero when the column pass reads the raw ring itself
+  case KH_STAGE_FFT1: return "kh_fft_cols|kh_fft_fwd_lds";    // first (or only) pass of the forward transform
+  case KH_STAGE_FFT2: return "kh_fft_rows";
+  case KH_STAGE_N0: return "kh_n0_pass1+kh_n0_final";         // zero when the second iteration rides in kh_back_a
+  case KH_STAGE_CHAN: return "kh_back_a|kh_chan_wave64|kh_filter_out";
+  case KH_STAGE_DEMOD: return "kh_fm_finish_w|kh_demod_linear|kh_demod_am";
   case KH_STAGE_CARRY: return "kh_carry";
   }
   return "";
