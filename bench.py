@@ -77,26 +77,33 @@ def stage_bytes(bincount, n0_rides):
 
 
 def cpu_baseline(x_host, rots, budget_s=12.0):
-    """the oracle (kind 'port': the CPU restatement, reference COPTS) on the same workload, single thread,
-    bounded sample.  TEST INFRASTRUCTURE used as a reported baseline only."""
+    """the oracle (kind 'port': the CPU restatement, reference COPTS) on the same workload, single thread, bounded
+    sample.  TEST INFRASTRUCTURE used as a reported baseline only."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import pipeline
-    pipe = pipeline.Pipeline(L, M, D, FS, compute_n0=True, n0_low=-5500.0, n0_high=5500.0, fast=True)
-    for r in rots:
-        pipe.add_channel(demod="fm", rotate=r, low=-5500.0, high=5500.0, kaiser_beta=3.0)
-    nb_avail = x_host.size // L
-    t0 = time.perf_counter()
-    nb = 0
-    while True:  # the sample repeats circularly; the NCO/demodulator state simply runs on
-        k = nb % nb_avail
-        pipe.run_block([x_host[k * L:(k + 1) * L]])
-        nb += 1
-        if time.perf_counter() - t0 > budget_s:
-            break
-    dt = time.perf_counter() - t0
-    return {"value": nb * L / dt / 1e6, "unit": "MS/s", "cores": 1, "kind": "port",
-            "sample": f"{nb} blocks of {L} samples, {C} NBFM channels, {dt:.1f} s of CPU time",
-            "ms_per_block": 1e3 * dt / nb}
+
+    def run(threads, budget):
+        pipe = pipeline.Pipeline(L, M, D, FS, compute_n0=True, n0_low=-5500.0, n0_high=5500.0, fast=True, threads=threads)
+        for r in rots:
+            pipe.add_channel(demod="fm", rotate=r, low=-5500.0, high=5500.0, kaiser_beta=3.0)
+        nb_avail = x_host.size // L
+        t0 = time.perf_counter()
+        nb = 0
+        while True:  # the sample repeats circularly; the NCO/demodulator state simply runs on
+            k = nb % nb_avail
+            pipe.run_block([x_host[k * L:(k + 1) * L]])
+            nb += 1
+            if time.perf_counter() - t0 > budget:
+                break
+        return nb, time.perf_counter() - t0
+
+    # One thread.  (pipeline.Pipeline(threads=n) partitions the channels over n threads behind one shared forward FFT, as
+    # SURVEY.md 8(d) sketches; it gains under 10 % here because the port's forward transform, mix and compute_n0 are
+    # four fifths of a block and run on one thread -- so the single-thread figure is the one reported.)
+    nb1, dt1 = run(1, budget_s)
+    return {"value": nb1 * L / dt1 / 1e6, "unit": "MS/s", "cores": 1, "kind": "port",
+            "sample": f"{nb1} blocks of {L} samples, {C} NBFM channels, {dt1:.1f} s of CPU time",
+            "ms_per_block": 1e3 * dt1 / nb1}
 
 
 def main():
@@ -171,6 +178,34 @@ def main():
     st = bank.stage_times()
     bank.profile(0)
 
+    # SURVEY.md 8(e) / BASELINE configs[3]: every GPU recomputes the forward FFT of the shared stream (option A, what the
+    # timed region does) against an RCCL broadcast over xGMI of the step's raw input (option B: saves host fan-out, not
+    # the FFT) or of its spectrum (option C: saves the FFT on the peers).  Timed here, outside the timed region.
+    probe = None
+    if dist is not None:
+        try:
+            def bcast_ms(t):
+                for _ in range(3):
+                    dist.broadcast(t, src=0)
+                torch.cuda.synchronize()
+                dist.barrier()
+                torch.cuda.synchronize()
+                tb = time.perf_counter()
+                reps = 10
+                for _ in range(reps):
+                    dist.broadcast(t, src=0)
+                torch.cuda.synchronize()
+                v = torch.tensor([(time.perf_counter() - tb) / reps], device=device, dtype=torch.float64)
+                dist.all_reduce(v, op=dist.ReduceOp.MAX)
+                return round(1e3 * float(v.item()), 4)
+            raw_like = x if rank == 0 else torch.empty_like(x)
+            spec_like = torch.empty(T * N, 2, device=device, dtype=torch.float32)
+            probe = {"broadcast_input_ms": bcast_ms(raw_like), "input_bytes": int(raw_like.numel() * 4),
+                     "broadcast_spectrum_ms": bcast_ms(spec_like), "spectrum_bytes": int(spec_like.numel() * 4)}
+            del spec_like
+        except Exception as e:  # the probe must never cost the bench line
+            probe = {"error": repr(e)}
+
     # sanity: the run demodulated something (squelch open on the strongest channel)
     stat = bank.status(C - 1, T)
     pcm = bank.pcm(C - 1, T)
@@ -227,6 +262,12 @@ def main():
                          "traffic_source": "profiles/r01_step3_hbm_traffic.json (separate rocprofv3 --pmc passes of this command)" if traffic else None,
                          "algorithmic_bytes_per_launch": sb[dom], "avg_launch_ms": dom_ms},
         }
+        if probe is not None:
+            fft_ms = sum(stages[k]["ms"] for k in ("ingest", "fft1", "fft2") if k in stages)
+            probe["recompute_forward_fft_ms"] = round(fft_ms, 4)
+            if "broadcast_spectrum_ms" in probe:
+                probe["cheaper"] = "recompute per GPU" if fft_ms <= probe["broadcast_spectrum_ms"] else "spectrum broadcast"
+            out["exchange_probe"] = probe
         if not args.no_cpu:
             nb = 6
             out["cpu_baseline"] = cpu_baseline(x[:nb * L].cpu().numpy().view(np.complex64).reshape(-1), rots)

@@ -79,8 +79,13 @@ class Pipeline:
     """One bank: n_inputs input streams, channels attached to them; the CPU twin of pyka9q.Bank."""
 
     def __init__(self, L, M, decimate, samprate, n_inputs=1, payload=0, compute_n0=False, n0_low=0.0, n0_high=0.0,
-                 fast=False):
+                 fast=False, threads=1):
         self.L, self.M, self.D, self.samprate = L, M, decimate, samprate
+        self.threads = threads
+        self.pool = None
+        if threads > 1:
+            from concurrent.futures import ThreadPoolExecutor
+            self.pool = ThreadPoolExecutor(max_workers=threads)
         self.N = L + M - 1
         self.fast = fast
         self.payload = payload
@@ -134,7 +139,10 @@ class Pipeline:
                     inp.n0 = v
                 n0 = inp.n0
             istat.append((if_power, n0))
-        outs = [ch.block() for ch in self.channels]
+        if self.pool is None:
+            outs = [ch.block() for ch in self.channels]
+        else:  # channels partitioned across threads, one shared forward FFT per block (the C calls release the GIL)
+            outs = list(self.pool.map(lambda ch: ch.block(), self.channels, chunksize=max(1, len(self.channels) // self.threads)))
         return outs, istat
 
     def spectrum(self, inp):
