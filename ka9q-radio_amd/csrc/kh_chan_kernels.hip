@@ -5,13 +5,12 @@
 //                          fold, backward DFT of N/D points), filter.c:197,206 (the last olen points are the output)
 //   demod_fm               fm.c:53-70 (block statistics), 85-112 (discriminator, threshold extension, de-emphasis)
 //
-// Mapping: R lanes own one (channel, block); a 64-lane wavefront carries 64/R of them and is a workgroup of its own,
-// so nothing here waits for another wave.  Every lane holds R points in registers: R-point transform, twiddle, ONE
-// transpose through LDS, R-point transform.  Of the R*R outputs only the upper half is wanted (overlap-save), which
-// after the second transform is the upper half of every lane's registers.  For FM channels the block statistics,
-// the conjugate-product discriminator (neighbour = lane-1: a rotation inside the group) and, after a second transpose
-// that gives every lane R/2 consecutive samples, the de-emphasis integrator from a zero carry-in follow without the
-// block ever leaving the wave.  kh_fm_finish (kh_demod_kernels.hip) then folds in what depends on earlier blocks.
+// Mapping: one 64-lane wavefront owns one (channel, block) and never waits for another wave (layout: see the comment
+// above ChanArgs).  Of the N_dec outputs only the upper half is wanted (overlap-save); it ends up as 8 samples per
+// lane, consecutive lanes holding consecutive samples.  For FM channels the block statistics, the conjugate-product
+// discriminator (neighbour = lane-1: a rotation of the wave) and, after a second transpose that gives every lane 8
+// consecutive samples, the de-emphasis integrator from a zero carry-in follow without the block ever leaving the wave.
+// kh_fm_finish_w (kh_demod_kernels.hip) then folds in what depends on earlier blocks.
 //
 // Roofline: HBM.  algorithmic bytes per (channel, block): 8*ND spectrum bins + 8*ND response (L2 after the first
 // block) + 8*olen baseband (if kept) + FM: 8*olen work + 32 statistics.
