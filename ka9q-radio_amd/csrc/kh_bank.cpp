@@ -531,14 +531,17 @@ static int enqueue_back(kh_bank *b, hipStream_t st, unsigned int nblocks, bool p
                                    b->keep_baseband},
                            1, ride ? &z : nullptr, &taken))
     return -1;
+  // kh_n0_final's work (one workgroup per input) rides in the FM finish launch when there is one of the wave form
+  N0FinalArgs nf;
+  bool const ride_final = ride && taken && b->n_fm > 0 && fm_finish_wave_usable(b->olen, nblocks);
   if (ride && launch_n0(st, n0spec, b->spec_stride, N, b->cfg.samprate, plan, b->d_energy[sp], echunks, L, b->d_n0state,
-                        b->d_n0acc[sp], b->d_istatus, nblocks, P, taken))
+                        b->d_n0acc[sp], b->d_istatus, nblocks, P, taken, ride_final ? &nf : nullptr))
     return -1;
   if (prof) hipEventRecord(b->ev[5], st);
   if (launch_demod(st, b->d_bb, b->bb_stride, b->olen, nblocks, C, b->d_ddesc, b->d_dstate,
                    b->keep_audio ? b->d_audio : nullptr, b->d_pcm, b->pcm_stride, b->cfg.pcm_big_endian, b->d_status,
                    b->T, b->d_lists, b->n_fm, b->d_lists + C, b->n_lin, b->d_lists + 2 * C, b->n_am,
-                   FmScratch{b->d_fmstat, b->d_fmwork, b->d_fmcarry, b->d_decaypow, b->fm_parity}))
+                   FmScratch{b->d_fmstat, b->d_fmwork, b->d_fmcarry, b->d_decaypow, b->fm_parity}, ride_final ? &nf : nullptr))
     return -1;
   if (prof) hipEventRecord(b->ev[6], st);
   return 0;

@@ -103,39 +103,46 @@ __global__ __launch_bounds__(256) void kh_n0_pass1(N0Pass1Args Z) {
 // one workgroup per input, one wave per block (16 waves: 16 blocks at a time; every lane issues all of its loads
 // before the first shuffle, so a block costs one memory round trip), then lane 0 applies radio.c:197-202 block by
 // block from LDS
-constexpr int N0_MAXB = 1024; // blocks per launch the smoothing pass can hold
 constexpr int N0_FT = 1024;
-__global__ __launch_bounds__(N0_FT) void kh_n0_final(const float *__restrict__ part, const float *__restrict__ energy_part,
-                                                     int echunks, int L, int N, int samprate, int valid, int have_n0,
-                                                     float *__restrict__ n0_state, kh_input_status *__restrict__ status,
-                                                     int nblocks) {
-  __shared__ float sv[N0_MAXB], se[N0_MAXB];
-  int const i = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const float *part1 = part + (size_t)gridDim.x * nblocks * N0_SLOTS;
-  for (int b = wave; b < nblocks; b += N0_FT / 64) {
-    size_t const pt = (size_t)i * nblocks + b;
-    const float *e = energy_part + pt * echunks;
-    float es = 0.f;
-    for (int k = lane; k < echunks; k += 64) es += e[k];
-    float s1 = 0.f, c1 = 0.f;
-    if (have_n0 && valid) {
-      float2 const sc = reinterpret_cast<const float2 *>(part1 + pt * (2 * N0_GX))[lane]; // N0_GX == 64: one per lane
-      s1 = sc.x;
-      c1 = sc.y;
+// one workgroup (any multiple of 64 threads) per input i; sv/se hold N0_MAXB floats each.  Every wave takes blocks
+// wave, wave + nwaves, ...; the loads of four blocks are issued before the first shuffle.
+__device__ __forceinline__ void n0_final_body(N0FinalArgs const &Z, int i, float *sv, float *se) {
+  int const lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
+  int const nblocks = Z.nblocks;
+  const float *part1 = Z.part + (size_t)Z.ninputs * nblocks * N0_SLOTS;
+  constexpr int U = 4;
+  for (int b0 = wave; b0 < nblocks; b0 += U * nwaves) {
+    float es[U], s1[U], c1[U];
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+      int const b = b0 + u * nwaves;
+      es[u] = s1[u] = c1[u] = 0.f;
+      if (b < nblocks) {
+        size_t const pt = (size_t)i * nblocks + b;
+        const float *e = Z.energy_part + pt * Z.echunks;
+        for (int k = lane; k < Z.echunks; k += 64) es[u] += e[k];
+        if (Z.have_n0 && Z.valid) {
+          float2 const sc = reinterpret_cast<const float2 *>(part1 + pt * (2 * N0_GX))[lane]; // N0_GX == 64: one per lane
+          s1[u] = sc.x;
+          c1[u] = sc.y;
+        }
+      }
     }
-    es = wave_sum(es);
-    s1 = wave_sum(s1);
-    c1 = wave_sum(c1);
-    float v = NAN;
-    if (have_n0) v = valid ? (s1 / c1) / ((float)N * samprate) : 0.f; // radio.c:433-435 ("Can this happen?"), 461, 464
-    if (lane == 0) {
-      se[b] = es / L; // radio.c:197
-      sv[b] = v;
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+      int const b = b0 + u * nwaves;
+      float const e = wave_sum(es[u]), s = wave_sum(s1[u]), c = wave_sum(c1[u]);
+      float v = NAN;
+      if (Z.have_n0) v = Z.valid ? (s / c) / ((float)Z.N * Z.samprate) : 0.f; // radio.c:433-435 ("Can this happen?"), 461, 464
+      if (lane == 0 && b < nblocks) {
+        se[b] = e / Z.L; // radio.c:197
+        sv[b] = v;
+      }
     }
   }
   __syncthreads();
-  if (threadIdx.x == 0 && have_n0) {
-    float n0 = n0_state[i];
+  if (threadIdx.x == 0 && Z.have_n0) {
+    float n0 = Z.n0_state[i];
     for (int b = 0; b < nblocks; b++) {
       float const v = sv[b];
       if (!isnan(n0))
@@ -144,13 +151,17 @@ __global__ __launch_bounds__(N0_FT) void kh_n0_final(const float *__restrict__ p
         n0 = v;
       sv[b] = n0;
     }
-    n0_state[i] = n0;
+    Z.n0_state[i] = n0;
   }
   __syncthreads();
-  for (int b = threadIdx.x; b < nblocks; b += N0_FT) {
-    status[(size_t)i * nblocks + b].if_power = se[b];
-    status[(size_t)i * nblocks + b].n0 = sv[b];
+  for (int b = threadIdx.x; b < nblocks; b += blockDim.x) {
+    Z.status[(size_t)i * nblocks + b].if_power = se[b];
+    Z.status[(size_t)i * nblocks + b].n0 = sv[b];
   }
+}
+__global__ __launch_bounds__(N0_FT) void kh_n0_final(N0FinalArgs Z) {
+  __shared__ float sv[N0_MAXB], se[N0_MAXB];
+  n0_final_body(Z, blockIdx.x, sv, se);
 }
 
 int n0_part_floats() { return N0_SLOTS + 2 * N0_GX; }
@@ -183,7 +194,7 @@ int n0_pass1_args(N0Pass1Args *z, const float2 *spec, size_t spec_in_stride, int
 }
 int launch_n0(hipStream_t st, const float2 *spec, size_t spec_in_stride, int N, int samprate, N0Plan plan,
               const float *energy_part, int echunks, int L, float *n0_state, float *part, void *input_status, int nblocks,
-              int ninputs, int pass1_done) {
+              int ninputs, int pass1_done, N0FinalArgs *final_out) {
   if (nblocks <= 0 || ninputs <= 0) return 0;
   if (nblocks > N0_MAXB) {
     set_error("at most %d blocks per launch", N0_MAXB);
@@ -195,8 +206,12 @@ int launch_n0(hipStream_t st, const float2 *spec, size_t spec_in_stride, int N, 
   int const valid = n0_pass1_args(&z, spec, spec_in_stride, N, plan, part, nblocks, ninputs);
   if (valid && !pass1_done)
     hipLaunchKernelGGL(kh_n0_pass1, dim3(N0_GX * nblocks * ninputs), dim3(256), 0, st, z);
-  hipLaunchKernelGGL(kh_n0_final, dim3(ninputs), dim3(N0_FT), 0, st, part, energy_part, echunks, L, N, samprate,
-                     valid, have_n0, n0_state, status, nblocks);
+  N0FinalArgs const F{part, energy_part, echunks, L, N, samprate, valid, have_n0, n0_state, status, nblocks, ninputs};
+  if (final_out) { // the caller lets it ride in the FM finish launch (launch_demod)
+    *final_out = F;
+    return 0;
+  }
+  hipLaunchKernelGGL(kh_n0_final, dim3(ninputs), dim3(N0_FT), 0, st, F);
   return KH_HIP(hipGetLastError()) ? 0 : -1;
 }
 
@@ -670,8 +685,14 @@ __device__ __forceinline__ void fm_finish_wave(FinishArgs const &F, int q, int l
   }
 }
 
+// workgroups [0, nfin) carry four finish wavefronts each; workgroups nfin + i (if any) are kh_n0_final's work for input i
 template <int K>
-__global__ __launch_bounds__(256) void kh_fm_finish_w(FinishArgs F, int npairs) {
+__global__ __launch_bounds__(256) void kh_fm_finish_w(FinishArgs F, int npairs, int nfin, N0FinalArgs Z) {
+  __shared__ float sv[N0_MAXB], se[N0_MAXB];
+  if ((int)blockIdx.x >= nfin) {
+    n0_final_body(Z, blockIdx.x - nfin, sv, se);
+    return;
+  }
   int const q = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (q < npairs) fm_finish_wave<K>(F, q, threadIdx.x & 63);
 }
@@ -899,10 +920,16 @@ __global__ __launch_bounds__(64) void kh_demod_am(const float2 *__restrict__ bas
   states[ch] = s;
 }
 
+// the wave form keeps 8 K registers of samples and one block's statistics per lane
+int fm_finish_wave_usable(int olen, int nblocks) {
+  static int const wave_env = getenv("KA9Q_HIP_FINISH_WAVE") ? atoi(getenv("KA9Q_HIP_FINISH_WAVE")) : 1; // A/B switch
+  return wave_env && (olen + 63) / 64 <= 16 && nblocks <= 64;
+}
+
 int launch_demod(hipStream_t st, float2 *baseband, size_t bb_stride, int olen, int nblocks, int nchan,
                  const DemodDesc *desc, DemodState *state, float *audio, int16_t *pcm, size_t pcm_stride,
                  int pcm_big_endian, void *status, int status_stride, const int *fm_list, int n_fm, const int *lin_list,
-                 int n_lin, const int *am_list, int n_am, const FmScratch &fm) {
+                 int n_lin, const int *am_list, int n_am, const FmScratch &fm, const N0FinalArgs *n0final) {
   (void)nchan;
   if (nblocks <= 0) return 0;
   kh_status *stt = static_cast<kh_status *>(status);
@@ -914,19 +941,21 @@ int launch_demod(hipStream_t st, float2 *baseband, size_t bb_stride, int olen, i
     FinishArgs const F{olen, nblocks, desc, state, fm.parity, fm.stat, status_stride, fm.work, bb_stride, fm.carry,
                        fm.decay_pow, audio, pcm, pcm_stride, pcm_big_endian, stt, status_stride, fm_list, n_fm};
     int const npairs = n_fm * nblocks;
-    dim3 const grid((npairs + 3) / 4);
+    int const nfin = (npairs + 3) / 4;
     int const K = (olen + 63) / 64;
-    static int const wave_env = getenv("KA9Q_HIP_FINISH_WAVE") ? atoi(getenv("KA9Q_HIP_FINISH_WAVE")) : 1; // A/B switch
-    if (!wave_env || K > 16 || nblocks > 64) // (the wave form keeps 8 K registers of samples and one block's statistics per lane)
+    bool const wave = fm_finish_wave_usable(olen, nblocks);
+    N0FinalArgs const Z = (wave && n0final) ? *n0final : N0FinalArgs{};
+    dim3 const grid(nfin + ((wave && n0final) ? n0final->ninputs : 0));
+    if (!wave)
       hipLaunchKernelGGL(kh_fm_finish, dim3(n_fm, nblocks), dim3(FMB_NT), olen * sizeof(float2), st, olen, nblocks, desc,
                          state, fm.parity, fm.stat, status_stride, fm.work, bb_stride, fm.carry, fm.decay_pow, audio, pcm,
                          pcm_stride, pcm_big_endian, stt, status_stride, fm_list);
     else if (K <= 4)
-      hipLaunchKernelGGL(kh_fm_finish_w<4>, grid, dim3(256), 0, st, F, npairs);
+      hipLaunchKernelGGL(kh_fm_finish_w<4>, grid, dim3(256), 0, st, F, npairs, nfin, Z);
     else if (K <= 8)
-      hipLaunchKernelGGL(kh_fm_finish_w<8>, grid, dim3(256), 0, st, F, npairs);
+      hipLaunchKernelGGL(kh_fm_finish_w<8>, grid, dim3(256), 0, st, F, npairs, nfin, Z);
     else
-      hipLaunchKernelGGL(kh_fm_finish_w<16>, grid, dim3(256), 0, st, F, npairs);
+      hipLaunchKernelGGL(kh_fm_finish_w<16>, grid, dim3(256), 0, st, F, npairs, nfin, Z);
   }
   if (n_lin > 0)
     hipLaunchKernelGGL(kh_demod_linear, dim3((n_lin + 63) / 64), dim3(64), 0, st, baseband, bb_stride, olen, nblocks,

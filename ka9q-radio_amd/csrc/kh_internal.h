@@ -9,6 +9,7 @@
 namespace kh {
 
 struct N0Pass1Args; // kh_n0.cuh
+struct N0FinalArgs; // kh_n0.cuh
 
 // ---------------------------------------------------------------- errors
 void set_error(const char *fmt, ...);
@@ -173,13 +174,17 @@ int n0_pass1_args(N0Pass1Args *z, const float2 *spec, size_t spec_in_stride, int
 int launch_n0(hipStream_t st, const float2 *spec, size_t spec_in_stride, int N, int samprate, N0Plan plan,
               const float *energy_part, int echunks /*partial sums per (input, block)*/, int L, float *n0_state,
               float *part /*n0_part_floats() per (input,block)*/, void *input_status, int nblocks, int ninputs,
-              int pass1_done = 0);
+              int pass1_done = 0, N0FinalArgs *final_out = nullptr);
+// final_out != nullptr: kh_n0_final is not launched; *final_out receives its arguments for launch_demod
 // demodulators + scaleclip
 int launch_demod(hipStream_t st, float2 *baseband, size_t bb_stride, int olen, int nblocks, int nchan,
                  const DemodDesc *desc, DemodState *state, float *audio, int16_t *pcm, size_t pcm_stride,
                  int pcm_big_endian, void *status /*kh_status[nchan][max_blocks]*/, int status_stride,
                  const int *fm_list, int n_fm, const int *lin_list, int n_lin, const int *am_list, int n_am,
-                 const FmScratch &fm);
+                 const FmScratch &fm, const N0FinalArgs *n0final = nullptr);
+// n0final (may be null): kh_n0_final's work rides in the FM finish launch; only valid if fm_finish_wave_usable() and n_fm > 0
+int fm_finish_wave_usable(int olen, int nblocks);
+
 // response design on the device (filter.c:481-568, 573-628, 631-702)
 int launch_make_kaiser(hipStream_t st, float *window_dev, int M, float beta);
 int launch_window_filter(hipStream_t st, float2 *resp_dev, int L, int M, float beta, int real_filter);

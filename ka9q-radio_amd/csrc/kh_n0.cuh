@@ -3,10 +3,12 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include "kh_internal.h"
+#include "../../include/ka9q_hip.h"
 
 namespace kh {
 
-constexpr int N0_GX = 64; // workgroups (slices) per (input, block)
+constexpr int N0_GX = 64;     // workgroups (slices) per (input, block)
+constexpr int N0_MAXB = 1024; // blocks per launch the smoothing pass can hold
 
 struct N0Pass1Args {
   const float2 *spec;
@@ -14,6 +16,14 @@ struct N0Pass1Args {
   int N, start, bincount; // radio.c:440-447: bins (start + n) mod N, n < bincount
   float *part;            // layout below
   int nblocks, ninputs, npart0, gx;
+};
+
+struct N0FinalArgs { // kh_n0_final: partial sums -> n0 per block, smoothing (radio.c:197-202), IF power
+  const float *part, *energy_part;
+  int echunks, L, N, samprate, valid, have_n0;
+  float *n0_state;
+  kh_input_status *status;
+  int nblocks, ninputs;
 };
 
 __device__ __forceinline__ float n0_wave_sum(float v) {

@@ -54,6 +54,25 @@ def test_rotate_indexing_bit_exact(hip, rotate):
     o.close()
 
 
+@pytest.mark.parametrize("out_type", [orc.COMPLEX, orc.CROSS_CONJ])
+@pytest.mark.parametrize("rotate", [0, 3, -700, 16383, -16383, 16384 - 512, 511 - 16384])
+def test_wave_resident_output_rotate_and_cross_conj(hip, out_type, rotate):
+    """N_dec = 1024 with olen = 512 takes the wave-resident kernel (kh_chan_kernels.hip): the same index arithmetic
+    (filter.c:274-289, including rotations that wrap around N in the middle of the channel) and the CROSS_CONJ fold
+    (filter.c:371-381), which that kernel does while loading."""
+    L, M, D = 8192, 8193, 16
+    g = hip.Filter(L, M, D, orc.COMPLEX, out_type)
+    o = orc.Filter(L, M, D, orc.COMPLEX, out_type)
+    g.set_filter(-0.2, 0.31, 3.0)
+    o.set_filter(-0.2, 0.31, 3.0)
+    x = _noise(2 * L, 13)
+    for b in range(2):
+        blk = x[b * L:(b + 1) * L]
+        assert rel_rms(g.execute(blk, rotate), o.execute(blk, rotate)) < TOL, b
+    g.close()
+    o.close()
+
+
 @pytest.mark.parametrize("in_type,out_type", [(orc.COMPLEX, orc.CROSS_CONJ), (orc.COMPLEX, orc.REAL),
                                               (orc.REAL, orc.COMPLEX), (orc.REAL, orc.REAL)])
 def test_type_combinations(hip, in_type, out_type):
