@@ -81,12 +81,14 @@ struct filter_out {
   unsigned int blocknum;
 };
 
-/* filter.c:57.  NULL on failure (the reference only asserts).  N = L+M-1 must be a power of two
- * between 64 and 2^22 in this implementation (the reference accepts any FFTW size). */
+/* filter.c:57.  NULL on failure (the reference only asserts).  N = L+M-1 must be a power of two in
+ * [256, 2^20], or an even number up to 8192 whose only prime factors are 2, 3, 5, 7 -- the sizes the
+ * reference's nextfastfft (misc.c:129-148) hands to main.c:326-330, e.g. 7680 at 192 kS/s (the
+ * reference itself accepts any FFTW size). */
 struct filter_in *create_filter_input(unsigned int L, unsigned int M, enum filtertype in_type);
 /* filter.c:163.  response may be NULL (set later with set_filter); if not NULL it must come from
  * ka9q_hip_alloc and becomes filter-owned.  NULL if master is NULL.  N/decimate must be a power of
- * two between 16 and 8192. */
+ * two in [256, 8192] or an even 2,3,5,7-smooth number up to 8192 (1920 for the default above). */
 struct filter_out *create_filter_output(struct filter_in *master, kh_cf32 *response, unsigned int decimate,
                                         enum filtertype out_type);
 /* filter.c:212: forward transform of the N-point buffer, blocknum++, wake the outputs, move the

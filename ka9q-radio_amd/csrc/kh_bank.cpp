@@ -173,8 +173,9 @@ kh_bank *kh_bank_create(const struct kh_bank_config *cfg) {
   if (!cfg) return nullptr;
   if (ensure_init()) return nullptr;
   unsigned const N = cfg->L + cfg->M - 1;
-  if (cfg->L == 0 || cfg->M == 0 || !is_pow2(N) || N < 256 || N > (1u << 20)) {
-    set_error("kh_bank_create: N = L+M-1 = %u must be a power of two in [256, 2^20]", N);
+  if (cfg->L == 0 || cfg->M == 0 || !((is_pow2(N) && N >= 256 && N <= (1u << 20)) || make_any_plan((int)N).npass)) {
+    set_error("kh_bank_create: N = L+M-1 = %u must be a power of two in [256, 2^20] or have only the factors 2, 3, 5, 7 and be "
+              "at most %d", N, KH_MAX_SMALL_N);
     return nullptr;
   }
   if (cfg->decimate == 0 || N % cfg->decimate || cfg->L % cfg->decimate) {
@@ -182,8 +183,8 @@ kh_bank *kh_bank_create(const struct kh_bank_config *cfg) {
     return nullptr;
   }
   unsigned const ND = N / cfg->decimate;
-  if (!is_pow2(ND) || ND < 256 || ND > 8192) {
-    set_error("kh_bank_create: N/decimate = %u must be a power of two in [256, 8192]", ND);
+  if (!((is_pow2(ND) && ND >= 256 && ND <= 8192) || make_any_plan((int)ND).npass)) {
+    set_error("kh_bank_create: N/decimate = %u must be a power of two in [256, 8192] or have only the factors 2, 3, 5, 7", ND);
     return nullptr;
   }
   if (cfg->n_inputs == 0 || cfg->n_channels == 0 || cfg->max_blocks == 0 || cfg->samprate <= 0) {

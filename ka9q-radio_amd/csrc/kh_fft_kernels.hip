@@ -9,6 +9,7 @@
 #include "kh_internal.h"
 #include "kh_fft.cuh"
 #include "kh_regfft.cuh"
+#include "kh_anyfft.cuh"
 #include "kh_fm.cuh"
 #include "../../include/ka9q_hip.h"
 #include <cstdlib>
@@ -16,6 +17,13 @@
 namespace kh {
 
 enum { FT_NONE = 0, FT_COMPLEX = 1, FT_CROSS_CONJ = 2, FT_REAL = 3 }; // filter.h:18-23
+
+// two LDS buffers of n points; above 64 KiB the kernel has to be told once
+template <typename K>
+static bool allow_big_lds(K kernel, size_t bytes) {
+  if (bytes <= 65536) return true;
+  return KH_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * KH_MAX_SMALL_N * (int)sizeof(float2)));
+}
 
 // ================================================================ forward FFT, N <= 8192: one workgroup per block
 // algorithmic bytes per launch: nblocks*ninputs*(8N read + 8N write)
@@ -60,6 +68,37 @@ __global__ __launch_bounds__(NT) void kh_fft_fwd_lds(const void *__restrict__ ti
   }
   if (n0.part != nullptr) { // uniform
     pw = block_sum<NT>(pw, red);
+    if (tid == 0) n0.part[((size_t)i * gridDim.x + b) * N0_SLOTS] = pw;
+  }
+}
+
+
+// forward FFT of any 2,3,5,7-smooth N <= 8192 (the reference's nextfastfft sizes): one workgroup per block, two LDS buffers
+__global__ __launch_bounds__(256) void kh_fft_fwd_any(const void *__restrict__ time, size_t in_stride, int real_input,
+                                                      float2 *__restrict__ spec, size_t spec_in_stride, int L,
+                                                      const float2 *__restrict__ tw, N0Fuse n0, AnyPlan plan) {
+  extern __shared__ __attribute__((aligned(16))) float2 dynf[];
+  __shared__ float red[4];
+  int const tid = threadIdx.x, R = plan.n;
+  int const b = blockIdx.x, i = blockIdx.y;
+  if (real_input) {
+    const float *src = static_cast<const float *>(time) + i * in_stride + (size_t)b * L;
+    for (int k = tid; k < R; k += 256) dynf[k] = make_float2(src[k], 0.f);
+  } else {
+    const float2 *src = static_cast<const float2 *>(time) + i * in_stride + (size_t)b * L;
+    for (int k = tid; k < R; k += 256) dynf[k] = src[k];
+  }
+  __syncthreads();
+  const float2 *res = any_fft<-1>(dynf, dynf + R, plan, tw, tid, 256);
+  float2 *dst = spec + i * spec_in_stride + (size_t)b * R;
+  float pw = 0.f;
+  for (int k = tid; k < R; k += 256) {
+    float2 const v = res[k];
+    dst[k] = v;
+    if (n0.part != nullptr && n0_bin_counts(k, R, n0)) pw += v.x * v.x + v.y * v.y;
+  }
+  if (n0.part != nullptr) { // uniform
+    pw = block_sum<256>(pw, red);
     if (tid == 0) n0.part[((size_t)i * gridDim.x + b) * N0_SLOTS] = pw;
   }
 }
@@ -488,8 +527,10 @@ int fused_ingest_tiles(int N) { // IF power partial sums the fused column pass l
 int launch_forward_fft(hipStream_t st, const void *time, size_t in_stride, int real_input, float2 *spec, float2 *tmp,
                        size_t spec_in_stride, int N, int L, int nblocks, int ninputs, hipEvent_t mid_event, N0Fuse n0,
                        const FftIngest *fi) {
-  if (N < 256 || (N & (N - 1)) || N > (1 << 20)) {
-    set_error("forward FFT size %d unsupported (power of two in [256, 2^20] required)", N);
+  bool const pow2 = N >= 256 && !(N & (N - 1)) && N <= (1 << 20);
+  if (!pow2 && !make_any_plan(N).npass) {
+    set_error("forward FFT size %d unsupported (a power of two in [256, 2^20], or factors 2, 3, 5, 7 and at most %d)", N,
+              KH_MAX_SMALL_N);
     return -1;
   }
   if (nblocks <= 0 || ninputs <= 0) return 0;
@@ -499,6 +540,17 @@ int launch_forward_fft(hipStream_t st, const void *time, size_t in_stride, int r
       return -1;
     }
     int rc = -1;
+    if (!pow2) { // the reference's nextfastfft sizes (main.c:326-330)
+      AnyPlan const plan = make_any_plan(N);
+      const float2 *tw = twiddle_table(N);
+      size_t const lds = 2 * (size_t)N * sizeof(float2);
+      if (!tw || !allow_big_lds(kh_fft_fwd_any, lds)) return -1;
+      hipLaunchKernelGGL(kh_fft_fwd_any, dim3(nblocks, ninputs), dim3(256), lds, st, time, in_stride, real_input, spec,
+                         spec_in_stride, L, tw, n0, plan);
+      rc = KH_HIP(hipGetLastError()) ? 0 : -1;
+      if (mid_event) hipEventRecord(mid_event, st);
+      return rc;
+    }
     switch (N) {
     case 256: rc = launch_small<256>(st, time, in_stride, real_input, spec, spec_in_stride, L, nblocks, ninputs, n0); break;
     case 512: rc = launch_small<512>(st, time, in_stride, real_input, spec, spec_in_stride, L, nblocks, ninputs, n0); break;
@@ -542,25 +594,31 @@ template <int ND, int NT>
 __global__ __launch_bounds__(NT) void kh_filter_out(const float2 *__restrict__ spec, size_t spec_in_stride, int N,
                                                     int in_real, const ChanDesc *__restrict__ chans,
                                                     const float2 *__restrict__ response, int olen, void *out,
-                                                    size_t out_stride, const float2 *__restrict__ tw, FmFront fm) {
-  __shared__ __attribute__((aligned(16))) float2 f[ND];
+                                                    size_t out_stride, const float2 *__restrict__ tw, FmFront fm,
+                                                    AnyPlan plan) {
+  // ND == 0: any 2,3,5,7-smooth size (plan.n), transform by any_fft in two LDS buffers of the launch's dynamic LDS
+  constexpr bool GEN = ND == 0;
+  extern __shared__ __attribute__((aligned(16))) float2 dynf[];
+  __shared__ __attribute__((aligned(16))) float2 statf[GEN ? 1 : ND];
+  float2 *f = GEN ? dynf : statf;
+  int const nd = GEN ? plan.n : ND;
   __shared__ float red[NT / 64 > 0 ? NT / 64 : 1];
   __shared__ double w_A[NT / 64 > 0 ? NT / 64 : 1], w_B[NT / 64 > 0 ? NT / 64 : 1];
   int const tid = threadIdx.x;
   int const ch = blockIdx.x, b = blockIdx.y;
   ChanDesc const cd = chans[ch];
   const float2 *fd = spec + (size_t)cd.input * spec_in_stride + (size_t)b * N;
-  const float2 *resp = response + (size_t)ch * ND;
+  const float2 *resp = response + (size_t)ch * nd;
   bool const out_real = cd.out_type == FT_REAL;
   int const rotate = cd.rotate;
 
   if (!in_real && !out_real) { // complex -> complex, filter.c:274-289
-    int m0 = N - ND / 2 + 1 + rotate;
+    int m0 = N - nd / 2 + 1 + rotate;
     if (m0 >= N) m0 -= N;
     if (m0 < 0) m0 += N;
-    for (int i = tid; i < ND; i += NT) {
-      int p = ND / 2 + 1 + i;
-      if (p >= ND) p -= ND;
+    for (int i = tid; i < nd; i += NT) {
+      int p = nd / 2 + 1 + i;
+      if (p >= nd) p -= nd;
       int m = m0 + i;
       if (m >= N) m -= N;
       f[p] = cmul(resp[p], fd[m]);
@@ -568,34 +626,34 @@ __global__ __launch_bounds__(NT) void kh_filter_out(const float2 *__restrict__ s
   } else {
     int m0 = rotate;
     if (m0 < 0) m0 += N;
-    if (in_real && out_real) { // real -> real, filter.c:290-299 (bins above ND/2 are rebuilt below)
-      for (int p = tid; p <= ND / 2; p += NT) {
+    if (in_real && out_real) { // real -> real, filter.c:290-299 (bins above nd/2 are rebuilt below)
+      for (int p = tid; p <= nd / 2; p += NT) {
         int m = m0 + p;
         if (m >= N) m -= N;
         f[p] = cmul(resp[p], fd[m]);
       }
     } else if (!in_real && out_real) { // complex -> real, filter.c:300-317
-      for (int p = tid; p <= ND / 2; p += NT) {
+      for (int p = tid; p <= nd / 2; p += NT) {
         int m = m0 + p;
         if (m >= N) m -= N;
         float2 v = cmul(resp[p], fd[m]);
-        if (p > 0 && p < ND / 2) v = cadd(v, cconj(cmul(resp[ND - p], fd[m])));
+        if (p > 0 && p < nd / 2) v = cadd(v, cconj(cmul(resp[nd - p], fd[m])));
         f[p] = v;
       }
     } else { // real -> complex, filter.c:318-335
-      for (int p = tid; p <= ND / 2; p += NT) {
+      for (int p = tid; p <= nd / 2; p += NT) {
         int m = m0 + p;
         if (m >= N) m -= N;
         float2 const x = fd[m];
         f[p] = cmul(resp[p], x);
-        if (p > 0 && p < ND / 2) f[ND - p] = cmul(resp[ND - p], cconj(x));
+        if (p > 0 && p < nd / 2) f[nd - p] = cmul(resp[nd - p], cconj(x));
       }
     }
   }
   __syncthreads();
   if (cd.out_type == FT_CROSS_CONJ) { // filter.c:371-381
-    for (int p = 1 + tid; p < ND / 2; p += NT) {
-      int const dn = ND - p;
+    for (int p = 1 + tid; p < nd / 2; p += NT) {
+      int const dn = nd - p;
       float2 const pos = f[p], neg = f[dn];
       f[p] = cadd(pos, cconj(neg));
       f[dn] = csub(neg, cconj(pos));
@@ -603,28 +661,31 @@ __global__ __launch_bounds__(NT) void kh_filter_out(const float2 *__restrict__ s
     __syncthreads();
   }
   if (out_real) { // c2r (filter.c:207,382): Hermitian extension, imaginary parts of DC and Nyquist ignored
-    for (int p = tid; p <= ND / 2; p += NT) {
+    for (int p = tid; p <= nd / 2; p += NT) {
       float2 v = f[p];
-      if (p == 0 || p == ND / 2)
+      if (p == 0 || p == nd / 2)
         f[p] = make_float2(v.x, 0.f);
       else
-        f[ND - p] = cconj(v);
+        f[nd - p] = cconj(v);
     }
     __syncthreads();
   }
-  lds_fft<ND, 1, NT, 1, 1, false, +1>(f, tw, tid);
+  if constexpr (GEN)
+    f = any_fft<+1>(f, f + nd, plan, tw, tid, NT);
+  else
+    lds_fft<ND, 1, NT, 1, 1, false, +1>(f, tw, tid);
   // the valid part of the circular convolution is the last olen points (filter.c:197,206)
   if (out_real) {
     float *o = static_cast<float *>(out) + (size_t)ch * out_stride + (size_t)b * olen;
-    for (int n = tid; n < olen; n += NT) o[n] = f[ND - olen + n].x;
+    for (int n = tid; n < olen; n += NT) o[n] = f[nd - olen + n].x;
   } else {
     bool const is_fm = fm.stat != nullptr && cd.fm_stats; // uniform
     if (!is_fm || fm.write_baseband) {
       float2 *o = static_cast<float2 *>(out) + (size_t)ch * out_stride + (size_t)b * olen;
-      for (int n = tid; n < olen; n += NT) o[n] = f[ND - olen + n];
+      for (int n = tid; n < olen; n += NT) o[n] = f[nd - olen + n];
     }
     if (is_fm) { // fm.c:53-70 and the block-local part of fm.c:85-112 while the block is still in LDS
-      float2 *y = f + (ND - olen);
+      float2 *y = f + (nd - olen);
       float bb = 0.f, sa = 0.f;
       for (int n = tid; n < olen; n += NT) {
         float2 const v = y[n];
@@ -663,7 +724,22 @@ static int launch_fo(hipStream_t st, const float2 *spec, size_t spec_in_stride, 
   const float2 *tw = twiddle_table(ND);
   if (!tw) return -1;
   hipLaunchKernelGGL((kh_filter_out<ND, NT>), dim3(nchan, nblocks), dim3(NT), 0, st, spec, spec_in_stride, N, in_real,
-                     chans, response, olen, out, out_stride, tw, fm);
+                     chans, response, olen, out, out_stride, tw, fm, AnyPlan{});
+  return KH_HIP(hipGetLastError()) ? 0 : -1;
+}
+static int launch_fo_any(hipStream_t st, const float2 *spec, size_t spec_in_stride, int N, int in_real, const ChanDesc *chans,
+                         const float2 *response, int ND, int olen, void *out, size_t out_stride, int nblocks, int nchan,
+                         FmFront const &fm) {
+  AnyPlan const plan = make_any_plan(ND);
+  const float2 *tw = twiddle_table(ND);
+  if (!plan.npass || !tw) {
+    set_error("decimated FFT size %d unsupported (factors 2, 3, 5, 7; at most %d)", ND, KH_MAX_SMALL_N);
+    return -1;
+  }
+  size_t const lds = 2 * (size_t)ND * sizeof(float2);
+  if (!allow_big_lds(kh_filter_out<0, 256>, lds)) return -1;
+  hipLaunchKernelGGL((kh_filter_out<0, 256>), dim3(nchan, nblocks), dim3(256), lds, st, spec, spec_in_stride, N, in_real,
+                     chans, response, olen, out, out_stride, tw, fm, plan);
   return KH_HIP(hipGetLastError()) ? 0 : -1;
 }
 
@@ -693,8 +769,7 @@ int launch_filter_output(hipStream_t st, const float2 *spec, size_t spec_in_stri
     FO(8192);
   }
 #undef FO
-  set_error("decimated FFT size %d unsupported (power of two in [256, 8192] required)", ND);
-  return -1;
+  return launch_fo_any(st, spec, spec_in_stride, N, in_real, chans, response, ND, olen, out, out_stride, nblocks, nchan, fm);
 }
 
 // ================================================================ response design (control path, but on the device)
@@ -750,29 +825,36 @@ int launch_brickwall(hipStream_t st, float2 *resp_dev, int ND, float low, float 
 // window, gain 1/N, zero pad, back to the frequency domain.  One workgroup.
 template <int ND, int NT>
 __global__ __launch_bounds__(NT) void kh_window_filter(float2 *resp, int M, float beta, int real_filter,
-                                                       const float2 *__restrict__ tw) {
-  __shared__ __attribute__((aligned(16))) float2 buf[ND];
-  constexpr int PT = ND / NT;
+                                                       const float2 *__restrict__ tw, AnyPlan plan) {
+  constexpr bool GEN = ND == 0; // as in kh_filter_out
+  extern __shared__ __attribute__((aligned(16))) float2 dynf[];
+  __shared__ __attribute__((aligned(16))) float2 statf[GEN ? 1 : ND];
+  float2 *buf = GEN ? dynf : statf;
+  int const nd = GEN ? plan.n : ND;
+  constexpr int PT = GEN ? (KH_MAX_SMALL_N / NT) : (ND / NT > 0 ? ND / NT : 1);
   int const tid = threadIdx.x;
-  if (real_filter) { // c2r input: ND/2+1 bins, Hermitian extension (filter.c:589-590)
-    for (int p = tid; p <= ND / 2; p += NT) {
+  if (real_filter) { // c2r input: nd/2+1 bins, Hermitian extension (filter.c:589-590)
+    for (int p = tid; p <= nd / 2; p += NT) {
       float2 v = resp[p];
-      if (p == 0 || p == ND / 2)
+      if (p == 0 || p == nd / 2)
         buf[p] = make_float2(v.x, 0.f);
       else {
         buf[p] = v;
-        buf[ND - p] = cconj(v);
+        buf[nd - p] = cconj(v);
       }
     }
   } else {
-    for (int n = tid; n < ND; n += NT) buf[n] = resp[n];
+    for (int n = tid; n < nd; n += NT) buf[n] = resp[n];
   }
   __syncthreads();
-  lds_fft<ND, 1, NT, 1, 1, false, +1>(buf, tw, tid);
+  if constexpr (GEN)
+    buf = any_fft<+1>(buf, buf == dynf ? dynf + nd : dynf, plan, tw, tid, NT);
+  else
+    lds_fft<ND, 1, NT, 1, 1, false, +1>(buf, tw, tid);
   float const numc = (float)(M_PI * (double)beta);
   float const inv_denom = (float)(1. / (double)dev_i0f(numc));
   float const pc = (float)(2.0 / (double)(M - 1));
-  float const gain = (float)(1. / (double)ND);
+  float const gain = (float)(1. / (double)nd);
   float2 v[PT];
 #pragma unroll
   for (int u = 0; u < PT; u++) {
@@ -781,10 +863,10 @@ __global__ __launch_bounds__(NT) void kh_window_filter(float2 *resp, int M, floa
     if (n < M) {
       // filter.c:543-544 runs n = M-1 .. 0 in place: a source index above n and below M has already
       // been replaced by its own windowed value when it is read.
-      int const src = (n - M / 2 + ND) % ND;
+      int const src = (n - M / 2 + nd) % nd;
       float2 s;
       if (src > n && src < M) {
-        int const src2 = (src - M / 2 + ND) % ND;
+        int const src2 = (src - M / 2 + nd) % nd;
         float const ws = dev_kaiser(src, M, numc, inv_denom, pc);
         float2 const o = buf[src2];
         s = make_float2(o.x * ws * gain, o.y * ws * gain);
@@ -799,10 +881,14 @@ __global__ __launch_bounds__(NT) void kh_window_filter(float2 *resp, int M, floa
   }
   __syncthreads();
 #pragma unroll
-  for (int u = 0; u < PT; u++) buf[tid + u * NT] = v[u];
+  for (int u = 0; u < PT; u++)
+    if (tid + u * NT < nd) buf[tid + u * NT] = v[u];
   __syncthreads();
-  lds_fft<ND, 1, NT, 1, 1, false, -1>(buf, tw, tid);
-  int const nout = real_filter ? ND / 2 + 1 : ND;
+  if constexpr (GEN)
+    buf = any_fft<-1>(buf, buf == dynf ? dynf + nd : dynf, plan, tw, tid, NT);
+  else
+    lds_fft<ND, 1, NT, 1, 1, false, -1>(buf, tw, tid);
+  int const nout = real_filter ? nd / 2 + 1 : nd;
   for (int n = tid; n < nout; n += NT) resp[n] = buf[n];
 }
 
@@ -811,7 +897,7 @@ static int launch_wf(hipStream_t st, float2 *resp, int M, float beta, int real_f
   constexpr int NT = (ND / 4 < 256) ? ND / 4 : 256;
   const float2 *tw = twiddle_table(ND);
   if (!tw) return -1;
-  hipLaunchKernelGGL((kh_window_filter<ND, NT>), dim3(1), dim3(NT), 0, st, resp, M, beta, real_filter, tw);
+  hipLaunchKernelGGL((kh_window_filter<ND, NT>), dim3(1), dim3(NT), 0, st, resp, M, beta, real_filter, tw, AnyPlan{});
   return KH_HIP(hipGetLastError()) ? 0 : -1;
 }
 int launch_window_filter(hipStream_t st, float2 *resp_dev, int L, int M, float beta, int real_filter) {
@@ -828,8 +914,16 @@ int launch_window_filter(hipStream_t st, float2 *resp_dev, int L, int M, float b
   case 4096: return launch_wf<4096>(st, resp_dev, M, beta, real_filter);
   case 8192: return launch_wf<8192>(st, resp_dev, M, beta, real_filter);
   }
-  set_error("window_filter: FFT size %d unsupported (power of two in [256, 8192] required)", ND);
-  return -1;
+  AnyPlan const plan = make_any_plan(ND);
+  const float2 *tw = twiddle_table(ND);
+  if (!plan.npass || !tw) {
+    set_error("window_filter: FFT size %d unsupported (factors 2, 3, 5, 7; at most %d)", ND, KH_MAX_SMALL_N);
+    return -1;
+  }
+  size_t const lds = 2 * (size_t)ND * sizeof(float2);
+  if (!allow_big_lds(kh_window_filter<0, 256>, lds)) return -1;
+  hipLaunchKernelGGL((kh_window_filter<0, 256>), dim3(1), dim3(256), lds, st, resp_dev, M, beta, real_filter, tw, plan);
+  return KH_HIP(hipGetLastError()) ? 0 : -1;
 }
 
 // noise_gain, filter.c:631-656: scale * sum |response|^2

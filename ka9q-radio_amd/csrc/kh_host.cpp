@@ -118,6 +118,21 @@ BigTwiddle big_twiddle(int n) {
 
 static bool is_pow2(unsigned v) { return v && !(v & (v - 1)); }
 
+AnyPlan make_any_plan(int n) {
+  AnyPlan p{};
+  if (n < 16 || n > KH_MAX_SMALL_N || (n & 1)) return p; // (even: the REAL layouts and the bin split use n/2)
+  int m = n, k = 0;
+  for (int r : {4, 2, 3, 5, 7})
+    while (m % r == 0 && k < 14) {
+      p.radix[k++] = r;
+      m /= r;
+    }
+  if (m != 1) return p;
+  p.n = n;
+  p.npass = k;
+  return p;
+}
+
 // ---------------------------------------------------------------- filter.h private state
 struct FilterInImpl {
   int N, L, M;
@@ -198,8 +213,9 @@ void ka9q_hip_free(void *p) {
 struct filter_in *create_filter_input(unsigned int L, unsigned int M, enum filtertype in_type) {
   if (ensure_init()) return nullptr;
   unsigned const N = L + M - 1;
-  if (L == 0 || M == 0 || !is_pow2(N) || N < 256 || N > (1u << 20)) {
-    set_error("create_filter_input: N = L+M-1 = %u must be a power of two in [256, 2^20]", N);
+  if (L == 0 || M == 0 || !((is_pow2(N) && N >= 256 && N <= (1u << 20)) || make_any_plan((int)N).npass)) {
+    set_error("create_filter_input: N = L+M-1 = %u must be a power of two in [256, 2^20] or have only the factors 2, 3, 5, 7 "
+              "and be at most %d", N, KH_MAX_SMALL_N);
     return nullptr;
   }
   if (in_type == REAL && N > KH_MAX_SMALL_N) {
@@ -266,8 +282,8 @@ struct filter_out *create_filter_output(struct filter_in *master, kh_cf32 *respo
   unsigned const ND = N / decimate;
   if ((N % decimate) != 0)
     fprintf(stderr, "Warning: FFT size %'u is not divisible by decimation ratio %d\n", N, decimate); // filter.c:172
-  if (!is_pow2(ND) || ND < 256 || ND > 8192 || (N % decimate) != 0) {
-    set_error("create_filter_output: N/decimate = %u must be a power of two in [256, 8192]", ND);
+  if ((N % decimate) != 0 || !((is_pow2(ND) && ND >= 256 && ND <= 8192) || make_any_plan((int)ND).npass)) {
+    set_error("create_filter_output: N/decimate = %u must be a power of two in [256, 8192] or have only the factors 2, 3, 5, 7", ND);
     return nullptr;
   }
   struct filter_out *slave = (struct filter_out *)calloc(1, sizeof(*slave));
@@ -467,8 +483,8 @@ static int window_common(int L, int M, kh_cf32 *response, float beta, int real_f
   if (response == nullptr) return -1;
   if (ensure_init()) return -1;
   int const N = L + M - 1;
-  if (N < 256 || N > 8192 || !is_pow2((unsigned)N)) {
-    set_error("window_filter: N = L+M-1 = %d must be a power of two in [256, 8192]", N);
+  if (!((N >= 256 && N <= 8192 && is_pow2((unsigned)N)) || make_any_plan(N).npass)) {
+    set_error("window_filter: N = L+M-1 = %d must be a power of two in [256, 8192] or have only the factors 2, 3, 5, 7", N);
     return -1;
   }
   size_t const count = real_filter ? N / 2 + 1 : N;

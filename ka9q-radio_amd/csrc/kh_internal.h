@@ -28,6 +28,14 @@ struct BigTwiddle {
 };
 BigTwiddle big_twiddle(int n);
 
+// ---------------------------------------------------------------- transforms of any 2,3,5,7-smooth size (kh_anyfft.cuh)
+struct AnyPlan {
+  int n, npass;      // npass == 0: n is not 2,3,5,7-smooth, or outside [16, KH_MAX_SMALL_N]
+  int radix[14];     // product n; 4s first, then 2, 3, 5, 7
+};
+AnyPlan make_any_plan(int n);
+inline bool is_pow2_int(int v) { return v > 0 && !(v & (v - 1)); }
+
 // ---------------------------------------------------------------- per-channel device records
 struct ChanDesc {     // one per channel, read by the filter-output kernel
   int input;          // index of the input spectrum

@@ -97,6 +97,17 @@ def test_fm_bank_192k_flat_and_deemph(hip):
         _run_pair(hip, L, M, D, fs, bank_chans, x.astype(np.complex64), T, calls, flat=flat)
 
 
+def test_fm_bank_reference_default_sizes(hip):
+    """What `radio` computes by default at 192 kS/s today: L = 3840, N = nextfastfft(2L-1) = 7680 = 2^9*3*5, M = 3841,
+    D = 4 -> N_dec = 1920 (main.c:326-330, misc.c:129-148): the mixed-radix transforms (kh_anyfft.cuh) under the whole FM
+    chain, with compute_n0, over two launches."""
+    fs, L, M, D = 192_000, 3840, 3841, 4
+    T, calls = 4, 2
+    x = synth.noise(T * calls * L, 0.01, 3) + synth.fm_carrier(0, T * calls * L, fs, 0.0, 0.5, 1000.0, 3000.0)
+    for flat in (0, 1):
+        _run_pair(hip, L, M, D, fs, [(0, 0, 0, 0)], x.astype(np.complex64), T, calls, flat=flat, n0=True)
+
+
 def test_fm_squelch_transitions_and_no_baseband_mode(hip):
     """A carrier keyed on and off block by block: the squelch opens, holds its one-block tail and closes (fm.c:73-78),
     `state` is zeroed while closed (fm.c:123), so sample 0 of a block is demodulated against the last sample of the

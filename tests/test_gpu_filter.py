@@ -17,7 +17,10 @@ def _noise(n, seed):
     return (rng.standard_normal(n) + 1j * rng.standard_normal(n)).astype(np.complex64) * np.float32(0.1)
 
 
-@pytest.mark.parametrize("L,M,D", [(3840, 4353, 4), (512, 513, 2), (131072, 131073, 256), (524288, 524289, 1024)])
+# (3840, 3841, 4) is what the reference derives by default today: N = nextfastfft(2L-1) = 7680 = 2^9*3*5 (main.c:326-330,
+# misc.c:129-148); (2800, 2801, 7) has factors 5 and 7; (960, 961, 1) is the 48 kS/s case without decimation
+@pytest.mark.parametrize("L,M,D", [(3840, 4353, 4), (512, 513, 2), (131072, 131073, 256), (524288, 524289, 1024),
+                                   (3840, 3841, 4), (2800, 2801, 7), (960, 961, 1)])
 def test_forward_spectrum_and_output(hip, L, M, D):
     g = hip.Filter(L, M, D)
     o = orc.Filter(L, M, D)
@@ -75,8 +78,9 @@ def test_wave_resident_output_rotate_and_cross_conj(hip, out_type, rotate):
 
 @pytest.mark.parametrize("in_type,out_type", [(orc.COMPLEX, orc.CROSS_CONJ), (orc.COMPLEX, orc.REAL),
                                               (orc.REAL, orc.COMPLEX), (orc.REAL, orc.REAL)])
-def test_type_combinations(hip, in_type, out_type):
-    L, M, D = 3840, 4353, 4
+@pytest.mark.parametrize("shape", [(3840, 4353, 4), (3840, 3841, 4)])
+def test_type_combinations(hip, in_type, out_type, shape):
+    L, M, D = shape
     g = hip.Filter(L, M, D, in_type, out_type)
     o = orc.Filter(L, M, D, in_type, out_type)
     g.set_filter(0.01, 0.15, 3.0)
@@ -128,7 +132,7 @@ def test_error_behaviour(hip):
     assert L.set_filter(None, 0.0, 0.1, 3.0) == -1  # filter.c:661-662
     assert not L.create_filter_output(None, None, 4, 1)  # filter.c:165-166
     assert np.isnan(L.noise_gain(None))            # filter.c:632-633
-    assert not L.create_filter_input(1000, 1001, 1)  # N = 2000: not a power of two -> refused, with a message
+    assert not L.create_filter_input(1000, 1003, 1)  # N = 2002 = 2*7*11*13: a factor beyond 7 -> refused, with a message
     assert "power of two" in hip.last_error()
     g = hip.Filter(3840, 4353, 4)
     assert L.set_filter(g.fout, float("nan"), 0.1, 3.0) == -1
