@@ -244,24 +244,25 @@ template <int PT, int CNT>
 __device__ __forceinline__ void ingest_tile(float2 (&v)[CNT], ColsIngest const &ing, int i, int s_lane, int rstep_elems,
                                             float gain) {
   using F = RawFmt<PT>;
-  constexpr int OOB = 0x7ffffff0; // beyond any ring: the buffer load returns zero without touching memory
   __amdgpu_buffer_rsrc_t const rr = make_rsrc(ing.raw + (size_t)i * ing.raw_stride, ing.raw_bytes);
-  if (__builtin_amdgcn_ballot_w64(s_lane < 0) == 0) { // wave-uniform
-    // every element of the wave is a new sample: one per-lane offset, the row offset travels in an SGPR
-    kh_u32x2 w[CNT];
+  // New samples: one running per-lane byte offset (wave-uniform row offsets would cost CNT scalar registers).  A
+  // sample before the launch (s < 0) makes the offset negative, i.e. huge as the unsigned number the buffer unit
+  // compares with the ring's size: the load returns zero without touching memory.
+  int const step = rstep_elems * F::BPS;
+  int voff = s_lane * F::BPS;
 #pragma unroll
-    for (int k = 0; k < CNT; k++) w[k] = F::fetch(rr, s_lane * F::BPS, k * rstep_elems * F::BPS);
-#pragma unroll
-    for (int k = 0; k < CNT; k++) v[k] = F::decode(w[k], gain);
-  } else { // the window reaches back into the history (block 0 of a launch, unless L < M-1)
-    __amdgpu_buffer_rsrc_t const rh = make_rsrc(ing.hist_in + (size_t)i * ing.hist_stride, (unsigned)ing.M1 * 8u);
+  for (int k = 0; k < CNT; k++) {
+    v[k] = F::decode(F::fetch(rr, voff, 0), gain);
+    voff += step;
+  }
+  // The window reaches back into the history only in the first block(s) of a launch: those lanes then replace their
+  // zeros by the history samples (masked loads straight into v[k]).
+  if (__builtin_amdgcn_ballot_w64(s_lane < 0) != 0) { // wave-uniform
+    const float2 *hist = ing.hist_in + (size_t)i * ing.hist_stride + ing.M1;
 #pragma unroll
     for (int k = 0; k < CNT; k++) {
       int const s = s_lane + k * rstep_elems;
-      kh_u32x2 const h = __builtin_amdgcn_raw_buffer_load_b64(rh, s < 0 ? (ing.M1 + s) * 8 : OOB, 0, 0);
-      kh_u32x2 const w = F::fetch(rr, s >= 0 ? s * F::BPS : OOB, 0);
-      float2 const x = F::decode(w, gain);
-      v[k] = s < 0 ? make_float2(u2f(h.x), u2f(h.y)) : x;
+      if (s < 0) v[k] = hist[s];
     }
   }
 }
@@ -513,15 +514,18 @@ static int ilog2(unsigned v) {
   return e;
 }
 
+// N = N1*N2 with N1 <= N2: for odd log2 the column pass gets the smaller transform -- kh_fft_cols<16,32,256> (N1 = 512)
+// runs at 5.2 TB/s, the 512-thread <32,32,512> (N1 = 1024) at 4.3
+static int four_step_n1(int N) { return 1 << (ilog2((unsigned)N) / 2); }
+
 int n0_partials(int N) { // first-pass partial sums the forward transform leaves per (input, block)
   if (N <= KH_MAX_SMALL_N) return 1;
-  int const e = ilog2((unsigned)N);
-  return (1 << ((e + 1) / 2)) / TILE_W;
+  return four_step_n1(N) / TILE_W; // one per row tile
 }
 
 int fused_ingest_tiles(int N) { // IF power partial sums the fused column pass leaves per (input, block); 0: no fused pass
   if (N <= KH_MAX_SMALL_N) return 0;
-  return (1 << (ilog2((unsigned)N) / 2)) / TILE_W;
+  return (N / four_step_n1(N)) / TILE_W; // one per column tile
 }
 
 int launch_forward_fft(hipStream_t st, const void *time, size_t in_stride, int real_input, float2 *spec, float2 *tmp,
@@ -567,7 +571,8 @@ int launch_forward_fft(hipStream_t st, const void *time, size_t in_stride, int r
     return -1;
   }
   int const e = ilog2((unsigned)N);
-  int const N1 = 1 << ((e + 1) / 2), N2 = 1 << (e / 2);
+  int const N1 = four_step_n1(N), N2 = N / N1;
+  (void)e;
   const float2 *t = static_cast<const float2 *>(time);
   int rc = -1;
   switch (N1) {
