@@ -304,15 +304,16 @@ __global__ __launch_bounds__(64) void kh_chan_wave64(ChanArgs A) {
   chan_wave64_body<CW_RA>(A, ex, blockIdx.x, threadIdx.x);
 }
 
-// Horizontal fusion for the bank: workgroups [0, nchan_wg) carry four (channel, block) wavefronts each, the rest are
+// Horizontal fusion for the bank: workgroups [0, nchan_wg) carry BACK_WAVES (channel, block) wavefronts each, the rest are
 // compute_n0's second iteration (radio.c:451-462, kh_n0.cuh) over N0_GX slices per (input, block).  The channel
 // waves wait on memory latency and use little bandwidth, the n0 workgroups stream the spectrum: in one launch they
 // share the chip instead of queueing behind one another.
-__global__ __launch_bounds__(256) void kh_back_a(ChanArgs A, N0Pass1Args Z, int nchan_wg) {
-  __shared__ float2 ex[4 * CW_LDS];
+constexpr int BACK_WAVES = 2; // channel wavefronts per workgroup: their LDS sets how many workgroups of either kind a CU holds
+__global__ __launch_bounds__(64 * BACK_WAVES) void kh_back_a(ChanArgs A, N0Pass1Args Z, int nchan_wg) {
+  __shared__ float2 ex[BACK_WAVES * CW_LDS];
   if ((int)blockIdx.x < nchan_wg) {
     int const wave = threadIdx.x >> 6;
-    int const q = blockIdx.x * 4 + wave;
+    int const q = blockIdx.x * BACK_WAVES + wave;
     if (q < A.npairs) chan_wave64_body<CW_RA>(A, ex + wave * CW_LDS, q, threadIdx.x & 63);
   } else {
     n0_pass1_body(Z, blockIdx.x - nchan_wg, reinterpret_cast<float *>(ex));
@@ -335,8 +336,9 @@ int launch_chan_wave(hipStream_t st, const float2 *spec, size_t spec_in_stride, 
   int const npairs = nchan * nblocks;
   ChanArgs const A{spec, spec_in_stride, N, chans, response, out, out_stride, tw, fm, nchan, npairs};
   if (n0) {
-    int const nchan_wg = (npairs + 3) / 4;
-    hipLaunchKernelGGL(kh_back_a, dim3(nchan_wg + n0->gx * n0->nblocks * n0->ninputs), dim3(256), 0, st, A, *n0, nchan_wg);
+    int const nchan_wg = (npairs + BACK_WAVES - 1) / BACK_WAVES;
+    hipLaunchKernelGGL(kh_back_a, dim3(nchan_wg + n0->gx * n0->nblocks * n0->ninputs), dim3(64 * BACK_WAVES), 0, st, A, *n0,
+                       nchan_wg);
   } else {
     hipLaunchKernelGGL(kh_chan_wave64, dim3(npairs), dim3(64), 0, st, A);
   }

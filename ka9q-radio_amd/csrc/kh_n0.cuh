@@ -33,11 +33,11 @@ __device__ __forceinline__ float n0_wave_sum(float v) {
 }
 
 // part layout: [0, PT*N0_SLOTS) first-pass sums (left by the forward transform); then PT*N0_GX pairs {sum1, count1}
-// (PT = ninputs*nblocks).  wg = slice + N0_GX*(block + nblocks*input); 256 threads; `sh` holds >= 8 floats.
+// (PT = ninputs*nblocks).  wg = slice + N0_GX*(block + nblocks*input); 128 or 256 threads; `sh` holds >= 8 floats.
 // algorithmic bytes: 8*bincount per (input, block)
 __device__ __forceinline__ void n0_pass1_body(N0Pass1Args const &Z, int wg, float *sh) {
   float *ps = sh, *pc = sh + 4;
-  int const tid = threadIdx.x;
+  int const tid = threadIdx.x, nt = blockDim.x, nw = nt >> 6;
   int const slice = wg % Z.gx, b = (wg / Z.gx) % Z.nblocks, i = wg / (Z.gx * Z.nblocks);
   const float2 *fd = Z.spec + (size_t)i * Z.spec_in_stride + (size_t)b * Z.N;
   size_t const pt = (size_t)i * Z.nblocks + b;
@@ -53,8 +53,8 @@ __device__ __forceinline__ void n0_pass1_body(N0Pass1Args const &Z, int wg, floa
   float s = 0.f, c = 0.f;
   // eight loads in flight per lane: when this shares a launch with the channel wavefronts their LDS footprint caps
   // the workgroups per CU, and one load at a time would leave the memory system idle
-  int const stride = Z.gx * 256;
-  for (int n0 = slice * 256 + tid; n0 < Z.bincount; n0 += 8 * stride) {
+  int const stride = Z.gx * nt;
+  for (int n0 = slice * nt + tid; n0 < Z.bincount; n0 += 8 * stride) {
     float2 x[8];
 #pragma unroll
     for (int u = 0; u < 8; u++) {
@@ -80,8 +80,10 @@ __device__ __forceinline__ void n0_pass1_body(N0Pass1Args const &Z, int wg, floa
   }
   __syncthreads();
   if (tid == 0) {
-    p1[2 * slice] = ps[0] + ps[1] + ps[2] + ps[3];
-    p1[2 * slice + 1] = pc[0] + pc[1] + pc[2] + pc[3];
+    float ss = ps[0], cc = pc[0];
+    for (int w = 1; w < nw; w++) ss += ps[w], cc += pc[w];
+    p1[2 * slice] = ss;
+    p1[2 * slice + 1] = cc;
   }
 }
 

@@ -293,3 +293,47 @@ def test_config5_full_256_pipelines_independent(hip):
         assert small.status(i, T).tobytes() == big.status(i, T).tobytes()
     small.close()
     big.close()
+
+
+def test_back_to_back_launches_match_synchronised_ones(hip):
+    """kh_bank_execute is asynchronous and the two halves of consecutive launches overlap on two streams (double-buffered
+    spectrum, IF-power and n0 partials; FM state by launch parity).  Six launches queued without a host sync in between
+    must leave bit for bit the PCM, status and input status of six launches each followed by kh_bank_sync -- there are
+    no atomics anywhere, so any difference is a hazard between launches."""
+    fs, L, M, D, C, T = 8_000_000, 131072, 131073, 256, 8, 4
+    N = L + M - 1
+    calls = 6
+    sigs = [(k - 4, 0.02 + 0.01 * k, 300.0 + 50 * k, 2500.0) for k in range(C)]
+    x = np.ascontiguousarray(synth.wideband_fm(3, T * calls * L, fs, N, sigs), np.complex64)
+    banks = []
+    for _ in range(2):
+        b = hip.Bank(L, M, D, 1, C, T, fs, compute_n0=1, n0_low=-5500.0, n0_high=5500.0)
+        for c, (k, *_r) in enumerate(sigs):
+            b.set_channel(c, demod=hip.KH_DEMOD_FM, rotate=synth.rotate_for(k, 12500.0, N, fs), low=-5500.0, high=5500.0,
+                          kaiser_beta=3.0)
+        banks.append(b)
+    a, q = banks
+    # the queued bank takes its input from device memory (a device-to-device copy ordered on the bank's front stream)
+    src = hip.Bank(L, M, D, 1, 1, T * calls, fs)  # only its raw ring is used: device-resident copy of the whole input
+    src.write_input(0, x)
+    xd, xcap = src.raw_device_ptr(0)
+    assert xcap >= x.size
+    for call in range(calls):
+        seg = x[call * T * L:(call + 1) * T * L]
+        a.write_input(0, seg)
+        a.execute(T)
+        a.sync()
+    ptr, cap = q.raw_device_ptr(0)
+    assert cap >= T * L
+    for call in range(calls):
+        # the raw ring is refilled by a device copy on the bank's front stream order: write_input with a device pointer
+        q.write_input_device(0, xd + 8 * call * T * L, T * L)
+        q.execute(T, sync=False)
+    q.sync()
+    for c in range(C):
+        assert np.array_equal(a.pcm(c, T), q.pcm(c, T)), c
+        assert a.status(c, T).tobytes() == q.status(c, T).tobytes(), c
+    assert a.input_status(0, T).tobytes() == q.input_status(0, T).tobytes()
+    a.close()
+    q.close()
+    src.close()
