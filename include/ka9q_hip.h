@@ -224,6 +224,31 @@ int kh_bank_keep_baseband(kh_bank *, int enable);
  * (nblocks, buffer parity) is seen and replayed from then on.  0 (default): plain launches -- with four to six
  * kernels per launch the replay costs the host more than the launches do (measured, tools/hostbound.py). */
 int kh_bank_use_graph(kh_bank *, int enable);
+/* PCM packetisation plan (audio.c:32-135): send_mono_output / send_stereo_output cut every block's PCM into chunks
+ * of at most 480 16-bit words, skip all-zero chunks (the RTP timestamp still advances), set the marker bit on the
+ * first packet after silence and number the packets that are sent.  With the plan enabled the bank leaves one record
+ * per chunk, so the host only prepends the RTP header and calls send(). */
+struct kh_rtp_chunk {
+  uint32_t timestamp;  /* rtp.timestamp of the chunk (audio.c:54,105) */
+  uint16_t seq;        /* rtp.seq, valid when send != 0 (audio.c:64,116) */
+  uint8_t marker;      /* 1: first packet after silence (audio.c:59-63,111-115) */
+  uint8_t send;        /* 0: all-zero chunk, nothing is sent (audio.c:53,77-78) */
+  uint32_t offset;     /* first word of the chunk in kh_bank_read_pcm's array */
+  uint16_t nwords;     /* 16-bit words in the chunk (<= 480) */
+  uint16_t reserved;
+};
+struct kh_rtp_state {   /* demod->output.rtp.{timestamp,seq,packets,bytes}, output.silent, output.samples */
+  uint32_t timestamp;
+  uint16_t seq;
+  uint16_t silent;
+  uint64_t packets, bytes, samples;
+};
+int kh_bank_rtp_enable(kh_bank *, int enable);                                   /* default 0 */
+int kh_bank_rtp_set_state(kh_bank *, unsigned int ch, const struct kh_rtp_state *);
+/* chunks of the last execute for channel ch, in order; *nchunks = nblocks * ceil(olen*channels/480) (0 for a channel
+ * without demodulator); *after = state after the last chunk.  Synchronises. */
+int kh_bank_read_rtp(kh_bank *, unsigned int ch, struct kh_rtp_chunk *out, size_t max_chunks, size_t *nchunks,
+                     struct kh_rtp_state *after);
 void *kh_bank_stream(kh_bank *); /* hipStream_t */
 /* per-kernel timing with HIP events on the bank's stream.  Stages: */
 enum kh_stage { KH_STAGE_INGEST = 0, KH_STAGE_FFT1, KH_STAGE_FFT2, KH_STAGE_N0, KH_STAGE_CHAN, KH_STAGE_DEMOD,

@@ -111,6 +111,10 @@ struct kh_bank {
   bool chans_dirty = true;
   unsigned last_blocks = 0;
   int keep_audio = 1, keep_baseband = 1;
+  int rtp = 0;                       // PCM packetisation plan (audio.c:32-135) after every launch
+  kh_rtp_chunk *d_rtp = nullptr;     // [C][rtp_stride]
+  kh_rtp_state *d_rtpstate = nullptr;
+  int rtp_stride = 0;
   // hipGraph cache: the kernel sequence of one execute call, captured the second time a shape is seen
   struct GraphEntry {
     unsigned nblocks;
@@ -151,7 +155,7 @@ int kh_bank_destroy(kh_bank *b) {
                   b->d_ddesc, b->d_dstate,  b->d_idesc,   b->d_bb,     b->d_audio,  b->d_pcm,    b->d_status,
                   b->d_istatus, b->d_energy[0], b->d_energy[1], b->d_n0acc[0], b->d_n0acc[1], b->d_n0state, b->d_scalar,
                   b->d_lists,
-                  b->d_fmstat, b->d_fmwork, b->d_fmcarry, b->d_decaypow};
+                  b->d_fmstat, b->d_fmwork, b->d_fmcarry, b->d_decaypow, b->d_rtp, b->d_rtpstate};
   for (void *p : ptrs)
     if (p) hipFree(p);
   for (auto &e : b->ev)
@@ -264,6 +268,9 @@ kh_bank *kh_bank_create(const struct kh_bank_config *cfg) {
   A(&b->d_fmwork, C * b->bb_stride * sizeof(FmWork), true);
   A(&b->d_fmcarry, C * T * sizeof(double), true);
   A(&b->d_decaypow, (b->olen + 1) * sizeof(double), false);
+  b->rtp_stride = (int)(T * ((2 * b->olen + 479) / 480)); // stereo: 2 words per output sample
+  A(&b->d_rtp, C * b->rtp_stride * sizeof(kh_rtp_chunk), true);
+  A(&b->d_rtpstate, C * sizeof(kh_rtp_state), true);
   for (auto &e : b->ev)
     if (ok) ok = KH_HIP(hipEventCreate(&e));
   if (ok) { // 0.99376949^k (fm.c:111), by repeated multiplication in long double
@@ -544,6 +551,9 @@ static int enqueue_back(kh_bank *b, hipStream_t st, unsigned int nblocks, bool p
                    b->T, b->d_lists, b->n_fm, b->d_lists + C, b->n_lin, b->d_lists + 2 * C, b->n_am,
                    FmScratch{b->d_fmstat, b->d_fmwork, b->d_fmcarry, b->d_decaypow, b->fm_parity}, ride_final ? &nf : nullptr))
     return -1;
+  if (b->rtp && launch_rtp_plan(st, b->d_pcm, b->pcm_stride, b->olen, nblocks, C, b->d_ddesc, b->d_rtp, b->rtp_stride,
+                                b->d_rtpstate))
+    return -1;
   if (prof) hipEventRecord(b->ev[6], st);
   return 0;
 }
@@ -731,6 +741,39 @@ int kh_bank_keep_audio(kh_bank *b, int enable) {
   if (!b) return -1;
   b->keep_audio = enable != 0;
   drop_graphs(b);
+  return 0;
+}
+int kh_bank_rtp_enable(kh_bank *b, int enable) {
+  if (!b) return -1;
+  b->rtp = enable != 0;
+  drop_graphs(b);
+  return 0;
+}
+int kh_bank_rtp_set_state(kh_bank *b, unsigned int ch, const struct kh_rtp_state *s) {
+  if (!b || !s || ch >= (unsigned)b->C) return -1;
+  if (!KH_HIP(hipMemcpyAsync(b->d_rtpstate + ch, s, sizeof(*s), hipMemcpyHostToDevice, b->stream))) return -1;
+  return KH_HIP(hipStreamSynchronize(b->stream)) ? 0 : -1;
+}
+int kh_bank_read_rtp(kh_bank *b, unsigned int ch, struct kh_rtp_chunk *out, size_t max_chunks, size_t *nchunks,
+                     struct kh_rtp_state *after) {
+  if (!b || ch >= (unsigned)b->C) return -1;
+  if (!b->rtp) {
+    set_error("kh_bank_read_rtp: the plan is not enabled (kh_bank_rtp_enable)");
+    return -1;
+  }
+  DemodDesc const &d = b->ddesc[ch];
+  int const chans = d.demod == KH_DEMOD_LINEAR ? d.channels : 1;
+  size_t const cpb = ((size_t)b->olen * chans + 479) / 480;
+  size_t const n = d.demod == KH_DEMOD_NONE ? 0 : b->last_blocks * cpb;
+  if (nchunks) *nchunks = n;
+  if (out) {
+    if (max_chunks < n) {
+      set_error("kh_bank_read_rtp: %zu chunks, room for %zu", n, max_chunks);
+      return -1;
+    }
+    if (n && read_back(b, out, b->d_rtp + (size_t)ch * b->rtp_stride, n * sizeof(kh_rtp_chunk))) return -1;
+  }
+  if (after && read_back(b, after, b->d_rtpstate + ch, sizeof(*after))) return -1;
   return 0;
 }
 int kh_bank_keep_baseband(kh_bank *b, int enable) {

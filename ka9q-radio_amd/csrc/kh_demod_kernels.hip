@@ -926,6 +926,71 @@ int fm_finish_wave_usable(int olen, int nblocks) {
   return wave_env && (olen + 63) / 64 <= 16 && nblocks <= 64;
 }
 
+// ================================================================ PCM packetisation plan: audio.c:32-135
+// One workgroup per channel.  Pass 1 (all waves): not_silent of every chunk = OR of its words (audio.c:48-52,99-103).
+// Pass 2 (one thread): the serial bookkeeping of audio.c:53-79,104-132 -- timestamp, sequence number, marker.
+constexpr int RTP_CHUNK = 480; // PCM_BUFSIZE, audio.c:19
+__global__ __launch_bounds__(256) void kh_rtp_plan(const int16_t *__restrict__ pcm, size_t pcm_stride, int olen, int nblocks,
+                                                   const DemodDesc *__restrict__ descs, kh_rtp_chunk *__restrict__ plan,
+                                                   int plan_stride, kh_rtp_state *__restrict__ states) {
+  int const ch = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  DemodDesc const d = descs[ch];
+  if (d.demod == KH_DEMOD_NONE) return;
+  int const chans = d.demod == KH_DEMOD_LINEAR ? d.channels : 1;
+  int const wpb = olen * chans;                         // words per block = one send_*_output call
+  int const cpb = (wpb + RTP_CHUNK - 1) / RTP_CHUNK;    // chunks per call
+  int const total = nblocks * cpb;
+  const int16_t *p = pcm + (size_t)ch * pcm_stride;
+  kh_rtp_chunk *out = plan + (size_t)ch * plan_stride;
+  for (int c = wave; c < total; c += 4) {
+    int const b = c / cpb, j = c - b * cpb;
+    int const off = b * wpb + j * RTP_CHUNK;
+    int const nw = wpb - j * RTP_CHUNK < RTP_CHUNK ? wpb - j * RTP_CHUNK : RTP_CHUNK;
+    int acc = 0;
+    for (int k = lane; k < nw; k += 64) acc |= p[off + k];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) acc |= __shfl_xor(acc, o, 64);
+    if (lane == 0) {
+      kh_rtp_chunk r;
+      r.timestamp = 0;
+      r.seq = 0;
+      r.marker = 0;
+      r.send = acc != 0;
+      r.offset = (uint32_t)off;
+      r.nwords = (uint16_t)nw;
+      r.reserved = 0;
+      out[c] = r;
+    }
+  }
+  __syncthreads(); // (the records were written by this workgroup: visible to it after the barrier)
+  if (tid != 0) return;
+  kh_rtp_state s = states[ch];
+  for (int c = 0; c < total; c++) {
+    kh_rtp_chunk r = out[c];
+    r.timestamp = s.timestamp;
+    s.timestamp += r.nwords / chans;                 // audio.c:55,106: sample (frame) count
+    if (r.send) {
+      s.packets++;
+      s.bytes += 2u * r.nwords;
+      r.marker = s.silent ? 1 : 0;
+      s.silent = 0;
+      r.seq = s.seq++;
+      s.samples += r.nwords / chans;
+    } else {
+      s.silent = 1;
+    }
+    out[c] = r;
+  }
+  states[ch] = s;
+}
+int launch_rtp_plan(hipStream_t st, const int16_t *pcm, size_t pcm_stride, int olen, int nblocks, int nchan,
+                    const DemodDesc *descs, void *plan, int plan_stride, void *states) {
+  if (nblocks <= 0 || nchan <= 0) return 0;
+  hipLaunchKernelGGL(kh_rtp_plan, dim3(nchan), dim3(256), 0, st, pcm, pcm_stride, olen, nblocks, descs,
+                     static_cast<kh_rtp_chunk *>(plan), plan_stride, static_cast<kh_rtp_state *>(states));
+  return KH_HIP(hipGetLastError()) ? 0 : -1;
+}
+
 int launch_demod(hipStream_t st, float2 *baseband, size_t bb_stride, int olen, int nblocks, int nchan,
                  const DemodDesc *desc, DemodState *state, float *audio, int16_t *pcm, size_t pcm_stride,
                  int pcm_big_endian, void *status, int status_stride, const int *fm_list, int n_fm, const int *lin_list,

@@ -193,6 +193,9 @@ int launch_demod(hipStream_t st, float2 *baseband, size_t bb_stride, int olen, i
 // n0final (may be null): kh_n0_final's work rides in the FM finish launch; only valid if fm_finish_wave_usable() and n_fm > 0
 int fm_finish_wave_usable(int olen, int nblocks);
 
+// audio.c:32-135: one kh_rtp_chunk per PCM chunk of <= 480 words (plan: [nchan][plan_stride]), kh_rtp_state per channel
+int launch_rtp_plan(hipStream_t st, const int16_t *pcm, size_t pcm_stride, int olen, int nblocks, int nchan,
+                    const DemodDesc *descs, void *plan, int plan_stride, void *states);
 // response design on the device (filter.c:481-568, 573-628, 631-702)
 int launch_make_kaiser(hipStream_t st, float *window_dev, int M, float beta);
 int launch_window_filter(hipStream_t st, float2 *resp_dev, int L, int M, float beta, int real_filter);

@@ -28,7 +28,7 @@ EXPORTS = [
     "kh_bank_execute", "kh_bank_sync", "kh_bank_read_baseband", "kh_bank_read_pcm", "kh_bank_read_audio",
     "kh_bank_read_status", "kh_bank_read_input_status", "kh_bank_read_spectrum", "kh_bank_read_response",
     "kh_bank_pcm_device_ptr", "kh_bank_keep_audio", "kh_bank_keep_baseband", "kh_bank_use_graph", "kh_bank_stream", "kh_bank_profile", "kh_bank_stage_times",
-    "kh_stage_kernel_name",
+    "kh_stage_kernel_name", "kh_bank_rtp_enable", "kh_bank_rtp_set_state", "kh_bank_read_rtp",
 ]
 
 
@@ -148,6 +148,9 @@ def lib():
     L.kh_bank_stream.argtypes = [C.c_void_p]
     L.kh_bank_profile.argtypes = [C.c_void_p, C.c_int]
     L.kh_bank_keep_audio.argtypes = [C.c_void_p, C.c_int]
+    L.kh_bank_rtp_enable.argtypes = [C.c_void_p, C.c_int]
+    L.kh_bank_rtp_set_state.argtypes = [C.c_void_p, C.c_uint, C.c_void_p]
+    L.kh_bank_read_rtp.argtypes = [C.c_void_p, C.c_uint, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t), C.c_void_p]
     L.kh_bank_keep_baseband.argtypes = [C.c_void_p, C.c_int]
     L.kh_bank_use_graph.argtypes = [C.c_void_p, C.c_int]
     L.kh_bank_stage_times.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_uint)]
@@ -351,6 +354,27 @@ class Bank:
         ng = C.c_float()
         _check(self.lib.kh_bank_read_response(self.h, ch, out.ctypes.data, C.byref(ng)), "kh_bank_read_response")
         return out, ng.value
+
+    RTP_CHUNK = np.dtype([("timestamp", "<u4"), ("seq", "<u2"), ("marker", "u1"), ("send", "u1"), ("offset", "<u4"),
+                          ("nwords", "<u2"), ("reserved", "<u2")])
+    RTP_STATE = np.dtype([("timestamp", "<u4"), ("seq", "<u2"), ("silent", "<u2"), ("packets", "<u8"), ("bytes", "<u8"),
+                          ("samples", "<u8")])
+
+    def rtp_enable(self, enable=1):
+        _check(self.lib.kh_bank_rtp_enable(self.h, int(enable)), "kh_bank_rtp_enable")
+
+    def rtp_set_state(self, ch, timestamp=0, seq=0, silent=0):
+        s = np.zeros(1, self.RTP_STATE)
+        s["timestamp"], s["seq"], s["silent"] = timestamp, seq, silent
+        _check(self.lib.kh_bank_rtp_set_state(self.h, ch, s.ctypes.data), "kh_bank_rtp_set_state")
+
+    def rtp(self, ch):
+        n = C.c_size_t()
+        _check(self.lib.kh_bank_read_rtp(self.h, ch, None, 0, C.byref(n), None), "kh_bank_read_rtp")
+        out = np.zeros(n.value, self.RTP_CHUNK)
+        after = np.zeros(1, self.RTP_STATE)
+        _check(self.lib.kh_bank_read_rtp(self.h, ch, out.ctypes.data, n.value, C.byref(n), after.ctypes.data), "kh_bank_read_rtp")
+        return out, after[0]
 
     def keep_audio(self, enable):
         _check(self.lib.kh_bank_keep_audio(self.h, int(enable)), "kh_bank_keep_audio")

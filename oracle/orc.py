@@ -362,6 +362,44 @@ def scaleclip(x, fast=False):
     return out
 
 
+class RtpPacketiser:
+    """send_mono_output / send_stereo_output of audio.c:32-135 without the socket: for every call (one block of PCM
+    words, already scaleclip'ed) the list of chunks (timestamp, seq, marker, send, offset, nwords).  Integer logic only."""
+    PCM_BUFSIZE = 480  # audio.c:19
+
+    def __init__(self, channels=1, timestamp=0, seq=0, silent=0):
+        self.channels = channels
+        self.timestamp, self.seq, self.silent = timestamp, seq, silent  # demod->output.rtp.*, output.silent
+        self.packets = self.bytes = self.samples = 0
+
+    def block(self, pcm_words, base_offset=0):
+        pcm_words = np.asarray(pcm_words)
+        out = []
+        size = pcm_words.size // self.channels  # `size` frames (audio.c:32,83)
+        pos = 0
+        while size > 0:
+            chunk = min(self.PCM_BUFSIZE, self.channels * size)  # audio.c:46,97
+            words = pcm_words[pos:pos + chunk]
+            not_silent = bool(np.any(words != 0))  # audio.c:48-52,99-103 (htons keeps zero zero)
+            ts = self.timestamp & 0xFFFFFFFF
+            self.timestamp = (self.timestamp + chunk // self.channels) & 0xFFFFFFFF  # audio.c:55,106
+            marker = seq = 0
+            if not_silent:  # audio.c:56-76,107-129
+                self.packets += 1
+                self.bytes += 2 * chunk
+                marker = 1 if self.silent else 0
+                self.silent = 0
+                seq = self.seq
+                self.seq = (self.seq + 1) & 0xFFFF
+                self.samples += chunk // self.channels
+            else:
+                self.silent = 1  # audio.c:77-78,130-131
+            out.append((ts, seq, marker, int(not_silent), base_offset + pos, chunk))
+            pos += chunk
+            size -= chunk // self.channels
+        return out
+
+
 def mix(doppler, lo2, x, fast=False):
     """radio.c:179-191 on a block; doppler may be None.  Returns (mixed, energy)."""
     x = np.ascontiguousarray(x, np.complex64)

@@ -160,3 +160,50 @@ def test_fm_squelch_transitions_and_no_baseband_mode(hip):
         assert seen == {0, 1}
         bank.close()
         lean.close()
+
+
+def test_rtp_packetisation_plan(hip):
+    """audio.c:32-135 on the device: a keyed FM carrier gives blocks of silence (closed squelch,
+    the de-emphasis tail decays below one LSB), a stereo linear channel gives 4 chunks of 240 frames per 960-sample block.
+    The plan must equal the packetiser restatement run over the bank's own PCM, chunk for chunk, across two launches
+    (timestamp, sequence number and the silent flag carry over), starting from a non-trivial RTP state."""
+    import orc
+    fs, L, M, D = 192_000, 3840, 4353, 4
+    olen = L // D
+    T, calls = 6, 2
+    n = T * calls * L
+    keyed = np.array([1, 1, 0, 0, 0, 1, 0, 0, 0, 0, 1, 1], np.float32)
+    x = (synth.noise(n, 0.0, 5) + np.repeat(keyed, L) * synth.fm_carrier(0, n, fs, 0.0, 0.4, 700.0, 2500.0)).astype(np.complex64)
+    bank = hip.Bank(L, M, D, 1, 3, T, fs)
+    bank.rtp_enable(1)
+    bank.set_channel(0, demod=hip.KH_DEMOD_FM, rotate=0, low=-5500.0, high=5500.0, kaiser_beta=3.0)
+    bank.set_channel(1, demod=hip.KH_DEMOD_LINEAR, rotate=0, low=-5000.0, high=5000.0, kaiser_beta=3.0, channels=2, agc=0,
+                     agc_gain=1.0)
+    bank.set_channel(2, rotate=0, low=-5000.0, high=5000.0)  # no demodulator: no PCM, no chunks
+    bank.rtp_set_state(0, timestamp=0xFFFFF000, seq=0xFFFE, silent=1)  # both counters wrap inside the run
+    ref = [orc.RtpPacketiser(1, 0xFFFFF000, 0xFFFE, 1), orc.RtpPacketiser(2)]
+    sent = [0, 0]
+    for call in range(calls):
+        bank.write_input(0, x[call * T * L:(call + 1) * T * L])
+        bank.execute(T)
+        for ch, chans in ((0, 1), (1, 2)):
+            pcm = bank.pcm(ch, T)  # (2 words per output sample for the stereo channel)
+            plan, after = bank.rtp(ch)
+            want = []
+            wpb = olen * chans
+            for b in range(T):
+                want += ref[ch].block(pcm[b * wpb:(b + 1) * wpb], base_offset=b * wpb)
+            assert len(plan) == len(want) == T * ((wpb + 479) // 480)
+            for got, w in zip(plan, want):
+                ts, seq, marker, send, off, nw = w
+                assert (int(got["timestamp"]), int(got["send"]), int(got["offset"]), int(got["nwords"])) == (ts, send, off, nw)
+                if send:
+                    assert (int(got["seq"]), int(got["marker"])) == (seq, marker)
+            r = ref[ch]
+            assert (int(after["timestamp"]), int(after["seq"]), int(after["silent"]), int(after["packets"]), int(after["bytes"]),
+                    int(after["samples"])) == (r.timestamp, r.seq, r.silent, r.packets, r.bytes, r.samples)
+            sent[ch] += int(plan["send"].sum())
+        assert len(bank.rtp(2)[0]) == 0
+    # the keyed carrier produced both sent and suppressed chunks, and at least one marker after silence
+    assert 0 < sent[0] < calls * T * 2
+    bank.close()
