@@ -33,38 +33,62 @@ static __device__ double fm_xi(double thetasq) { // fm.c:180-186
   t *= t;
   return 2 + thetasq - (0.125 * M_PI) * exp(-0.5 * thetasq) * t;
 }
-// fm_xi on [0, 100] from a piecewise Chebyshev expansion (tools/fit_fm_xi.py; within 6e-13 of the series above):
-// ~50 fp64 operations instead of two 40-term series with a division per term and an exp.  fm_snr's fixed-point
-// iteration below runs it 3 times for a strong signal, 30 and more for a block of noise (r just above pi/(4-pi)),
-// all of it on one lane's critical path.  Outside [0, 100] (never reached from fm_snr) the series is used.
+// fm_snr (fm.c:190-205): the reference's fixed-point iteration thetasq <- xi(thetasq) (1 + r) - 2, run until two
+// iterates differ by at most .001.  It takes 3 rounds for a strong signal and 30 to several hundred for a block of
+// noise (r just above pi/(4-pi)) -- an idle channel is the expensive case -- and every round waits for the one before,
+// so what counts is the latency of one round.  xi on [0, 100] comes from piecewise degree-11 polynomials
+// (tools/fit_fm_xi.py; within 2e-14 (2 + thetasq) of the series above) evaluated by Estrin's scheme: about seven
+// dependent fp64 operations a round instead of two 40-term series with a division per term and an exp.  The iterates
+// move slowly, so the coefficients of the current segment stay in registers and are reloaded (scalar loads: the
+// argument is the same in every lane) only when an iterate leaves the segment.  Outside [0, 100] (not reached from
+// fm_snr's own range checks) the series is used.
 static __constant__ double kh_xi_edges[KH_XI_SEGS + 1] = KH_XI_EDGES;
 static __constant__ double kh_xi_coeffs[KH_XI_SEGS][KH_XI_DEG + 1] = KH_XI_COEFFS;
-static __device__ double fm_xi_fast(double thetasq) {
-  if (!(thetasq >= 0.0 && thetasq <= 100.0)) return fm_xi(thetasq);
-  int seg = 0;
-#pragma unroll
-  for (int k = 1; k < KH_XI_SEGS; k++) seg += thetasq > kh_xi_edges[k];
-  double const a = kh_xi_edges[seg], b = kh_xi_edges[seg + 1];
-  double const x = (2.0 * thetasq - a - b) / (b - a);
-  const double *c = kh_xi_coeffs[seg];
-  double b1 = 0.0, b2 = 0.0;
-#pragma unroll
-  for (int k = KH_XI_DEG; k >= 1; k--) { // Clenshaw
-    double const t = fma(2.0 * x, b1, c[k] - b2);
-    b2 = b1;
-    b1 = t;
-  }
-  return fma(x, b1, c[0] - b2);
+static __constant__ int kh_xi_lut[KH_XI_NLUT] = KH_XI_LUT;
+static_assert(KH_XI_DEG == 11, "fm_snr's Estrin evaluation is written for degree 11");
+
+__device__ __forceinline__ double wave_uniform(double v) { // the first active lane's value, as a scalar
+  int const lo = __builtin_amdgcn_readfirstlane(__double2loint(v)), hi = __builtin_amdgcn_readfirstlane(__double2hiint(v));
+  return __hiloint2double(hi, lo);
 }
+
+// r must be the same in every active lane of the wavefront (both callers pass a wavefront-wide reduction).
 static __device__ double fm_snr(double r) { // fm.c:190-205
+  r = wave_uniform(r);
   double thetasq = r;
   double othetasq = r + 10;
   if (r <= M_PI / (4 - M_PI)) return 0;
   if (r > 100) return r;
+  double const r1 = 1 + r;
+  double lo = 1.0, hi = 0.0, mid = 0.0, scale = 0.0, c[KH_XI_DEG + 1]; // empty segment: the first round loads one
+#pragma unroll
+  for (int k = 0; k <= KH_XI_DEG; k++) c[k] = 0.0;
   int guard = 0; // the reference loop has no bound; NaN input falls through both tests above and exits here
   while (fabs(thetasq - othetasq) > .001 && guard++ < 10000) {
     othetasq = thetasq;
-    thetasq = fm_xi_fast(thetasq) * (1 + r) - 2;
+    if (!(thetasq >= 0.0 && thetasq <= 100.0)) {
+      thetasq = fm_xi(thetasq) * r1 - 2;
+      continue;
+    }
+    if (!(thetasq >= lo && thetasq < hi)) {
+      int g = (int)(thetasq * (1.0 / KH_XI_GRID));
+      g = __builtin_amdgcn_readfirstlane(g < KH_XI_NLUT ? g : KH_XI_NLUT - 1);
+      int const seg = kh_xi_lut[g];
+      double const e1 = kh_xi_edges[seg + 1];
+      lo = kh_xi_edges[seg];
+      hi = seg == KH_XI_SEGS - 1 ? 101.0 : e1; // thetasq == 100 belongs to the last segment
+      mid = 0.5 * (lo + e1);
+      scale = 2.0 / (e1 - lo);
+#pragma unroll
+      for (int k = 0; k <= KH_XI_DEG; k++) c[k] = kh_xi_coeffs[seg][k];
+    }
+    double const u = (thetasq - mid) * scale;
+    double const u2 = u * u, u4 = u2 * u2, u8 = u4 * u4;
+    double const p01 = fma(c[1], u, c[0]), p23 = fma(c[3], u, c[2]), p45 = fma(c[5], u, c[4]);
+    double const p67 = fma(c[7], u, c[6]), p89 = fma(c[9], u, c[8]), pab = fma(c[11], u, c[10]);
+    double const q0 = fma(p23, u2, p01), q1 = fma(p67, u2, p45), q2 = fma(pab, u2, p89);
+    double const xi = fma(q2, u8, fma(q1, u4, q0));
+    thetasq = xi * r1 - 2;
   }
   return thetasq;
 }

@@ -68,7 +68,7 @@ def orc_scaleclip(a):
 
 
 def test_fm_bank_8MSps(hip):
-    """config 2 shape (8 MS/s, N = 2^18, D = 256 -> 31.25 kS/s), 6 carriers + 1 empty channel, two launches
+    """config 2 shape (8 MS/s, N = 2^18, D = 256 -> 31.25 kS/s), 6 carriers + 12 empty channels, two launches
     of 3 blocks: exercises the four-step FFT, the rotate indexing, the squelch and the state carry."""
     fs, L, M, D = 8_000_000, 131072, 131073, 256
     N = L + M - 1
@@ -76,10 +76,12 @@ def test_fm_bank_8MSps(hip):
             (2, 0.03, 700.0, 1500.0), (4, 0.015, 900.0, 3000.0)]
     T, calls = 3, 2
     x = synth.wideband_fm(0, T * calls * L, fs, N, sigs)
-    chans = sigs + [(9, 0, 0, 0)]  # channel 9: noise only, squelch stays closed
+    # slots 9 .. 20: noise only, squelch stays closed.  Their amplitude statistics sit just above fm_snr's threshold
+    # r = pi/(4-pi), where its iteration runs longest (72 such blocks here; the status bar of 1e-4 applies to snr)
+    chans = sigs + [(k, 0, 0, 0) for k in range(9, 21)]
     res = _run_pair(hip, L, M, D, fs, chans, x, T, calls, n0=True)
-    closed = [r for r in res if r[0] == 6]
-    assert all(r[2] == 0 for r in closed)
+    closed = [r for r in res if r[0] >= 6]
+    assert len(closed) == 12 * T * calls and all(r[2] == 0 for r in closed)
     opened = [r for r in res if r[0] == 3 and r[1] >= 2]
     assert all(abs(r[3]["pdeviation"] - 2500) < 150 for r in opened)
 
