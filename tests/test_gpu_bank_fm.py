@@ -52,7 +52,12 @@ def _run_pair(hip, L, M, D, fs, chans, x, nblocks_per_call, calls, flat=0, n0=Fa
                 st = g_st[c][b]
                 for key in ("bb_power", "snr", "output_level"):
                     ref = sig[key]
-                    assert abs(st[key] - ref) <= 1e-4 * abs(ref) + 1e-12, (key, c, b, st[key], ref)
+                    # snr: 1e-4 of max(|ref|, 1).  Just above fm_snr's threshold the iteration converges with a
+                    # ratio close to 1 and stops on a difference of .001 (fm.c:198), so a last-bit change of
+                    # r = avg^2/var (fp32 sums in another order) moves a result of ~0.07 by a few 1e-5; the squelch
+                    # compares snr with 4 (fm.c:73)
+                    floor = 1e-4 if key == "snr" else 1e-12
+                    assert abs(st[key] - ref) <= 1e-4 * abs(ref) + floor, (key, c, b, st[key], ref)
                 res.append((c, b, int(st["squelch_open"]), sig))
                 if st["squelch_open"] or sig["snr"] > 4:
                     for key in ("foffset", "pdeviation"):
