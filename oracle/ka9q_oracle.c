@@ -967,6 +967,111 @@ int orc_packetise(struct orc_pcm_state *st, const float *buffer, int size, int s
   return nchunks;
 }
 
+/* =========================================================== packet.c (AFSK-1200 demodulator, HDLC), ax25.c (CRC) */
+void orc_pcm_to_real(const int16_t *pcm_be, float *out, int n) { /* packet.c:340-343 */
+  float const SCALE = 1. / 32768; /* packet.c:43 */
+  for (int i = 0; i < n; i++) {
+    /* ntohs() yields an UNSIGNED short, so a negative sample s arrives as s + 65536: the real signal is
+     * s/32768 + 2 [s < 0].  The 100 Hz .. 4 kHz analytic filter removes the mean; what is left acts like a limiter. */
+    uint16_t const host = swap16((uint16_t)pcm_be[i]);
+    out[i] = host * SCALE;
+  }
+}
+int orc_crc_good(const unsigned char *frame, int length) { /* ax25.c:140-156 */
+  unsigned int const crc_poly = 0x8408;
+  unsigned short crc = 0xffff;
+  while (length-- > 0) {
+    unsigned char byte = *frame++;
+    for (int i = 0; i < 8; i++) {
+      unsigned short feedback = 0;
+      if ((crc ^ byte) & 1) feedback = crc_poly;
+      crc = (crc >> 1) ^ feedback;
+      byte >>= 1;
+    }
+  }
+  return crc == 0xf0b8;
+}
+void orc_afsk_init(struct orc_afsk_state *st) { /* packet.c:410-435 */
+  float const Samprate = 48000; /* packet.c:49 */
+  memset(st, 0, sizeof *st);
+  orc_set_osc(&st->mark, -1200. / Samprate, 0.0);  /* packet.c:414 */
+  orc_set_osc(&st->space, -2200. / Samprate, 0.0); /* packet.c:419 */
+}
+int orc_afsk_block(struct orc_afsk_state *st, const float complex *y, int n_in, int sample_base,
+                   struct orc_ax25_frame *out, int maxframes, struct orc_afsk_bit *bits, int maxbits, int *nbits) {
+  int const Samppbit = ORC_AFSK_SAMPPBIT;
+  int nframes = 0, nb = 0;
+  for (int n = 0; n < n_in; n++) { /* packet.c:440-544 */
+    float complex s;
+    s = y[n] * orc_step_osc(&st->mark); /* complex float x complex double, rounded to float on assignment */
+    st->mark_accum += s;
+    st->mark_offset_accum += s;
+    s = y[n] * orc_step_osc(&st->space);
+    st->space_accum += s;
+    st->space_offset_accum += s;
+    if (++st->symphase == Samppbit / 2) {
+      st->mid_val = cnrmf_(st->mark_offset_accum) - cnrmf_(st->space_offset_accum);
+      st->mark_offset_accum = st->space_offset_accum = 0;
+    }
+    if (st->symphase < Samppbit) continue;
+    st->symphase = 0;
+    float cur_val = cnrmf_(st->mark_accum) - cnrmf_(st->space_accum);
+    st->mark_accum = st->space_accum = 0;
+    if (bits && nb < maxbits) {
+      bits[nb].sample = sample_base + n;
+      bits[nb].cur_val = cur_val;
+    }
+    nb++;
+    if (cur_val * st->last_val < 0) {
+      st->symphase += ((cur_val - st->last_val) * st->mid_val) > 0 ? +1 : -1; /* packet.c:469 */
+      if (st->ones == 6) { /* flag */
+        if (st->flagsync) {
+          st->frame_bit -= 7;
+          int bytes = st->frame_bit / 8;
+          /* the reference indexes hdlc_frame[1024] without a bound; frames that would not fit are dropped here */
+          if (bytes > 0 && bytes <= ORC_AFSK_FRAME_MAX && orc_crc_good(st->hdlc_frame, bytes)) {
+            if (nframes < maxframes) {
+              struct orc_ax25_frame *f = &out[nframes];
+              f->sample = sample_base + n;
+              f->bytes = bytes;
+              f->seq = st->out_seq;
+              f->timestamp = st->out_timestamp;
+              memset(f->data, 0, sizeof f->data);
+              memcpy(f->data, st->hdlc_frame, bytes);
+              nframes++;
+            }
+            st->out_seq++;                 /* packet.c:498 */
+            st->out_timestamp += bytes;    /* packet.c:501 */
+            st->out_packets++;             /* packet.c:510-511 */
+            st->out_bytes += bytes;
+          }
+        }
+        memset(st->hdlc_frame, 0, sizeof st->hdlc_frame); /* packet.c:514-517 */
+        st->frame_bit = 0;
+        st->flagsync = 1;
+      } else if (st->ones == 5) {
+        /* stuffed zero */
+      } else if (st->ones < 5) {
+        if (st->flagsync) st->frame_bit++;
+      }
+      st->ones = 0;
+    } else {
+      if (++st->ones == 7) { /* abort */
+        memset(st->hdlc_frame, 0, sizeof st->hdlc_frame);
+        st->frame_bit = 0;
+        st->flagsync = 0;
+      } else if (st->flagsync) {
+        if (st->frame_bit >= 0 && st->frame_bit / 8 < ORC_AFSK_FRAME_MAX)
+          st->hdlc_frame[st->frame_bit / 8] |= 1 << (st->frame_bit % 8);
+        st->frame_bit++;
+      }
+    }
+    st->last_val = cur_val;
+  }
+  if (nbits) *nbits = nb;
+  return nframes;
+}
+
 /* =========================================================== misc.c */
 uint32_t orc_nextfastfft(uint32_t n) { /* misc.c:129-148 */
   uint64_t result = 4288306050ULL;

@@ -230,6 +230,41 @@ struct orc_pcm_state { uint32_t timestamp; uint16_t seq; int silent; long long p
 int orc_packetise(struct orc_pcm_state *st, const float *buffer, int size, int stereo, int16_t *pcm_be,
                   int *sent, int *marker, uint32_t *ts, int maxchunks);
 
+/* ---------------------------------------------------------------- packet.c (AFSK-1200 + HDLC) and ax25.c (CRC) */
+#define ORC_AFSK_AL 1000        /* packet.c:46 */
+#define ORC_AFSK_AM 1049        /* packet.c:48 */
+#define ORC_AFSK_SAMPPBIT 40    /* packet.c:52 */
+#define ORC_AFSK_FRAME_MAX 1024 /* packet.c:431 */
+struct orc_afsk_state {         /* the locals of decode_task, packet.c:410-435, and sp->rtp_state_out */
+  struct orc_osc mark, space;
+  int symphase;
+  float complex mark_accum, space_accum, mark_offset_accum, space_offset_accum;
+  float last_val, mid_val;
+  unsigned char hdlc_frame[ORC_AFSK_FRAME_MAX];
+  int frame_bit, flagsync, ones;
+  uint32_t out_timestamp;
+  uint16_t out_seq;
+  long long out_packets, out_bytes;
+};
+struct orc_ax25_frame {         /* one frame that passed crc_good (packet.c:477), as handed to send() (506-509) */
+  int sample;                   /* index, within the call, of the sample whose bit closed the frame */
+  int bytes;                    /* frame length including the two CRC bytes */
+  uint32_t timestamp;           /* RTP header fields, packet.c:498-502 */
+  uint16_t seq;
+  unsigned char data[ORC_AFSK_FRAME_MAX];
+};
+struct orc_afsk_bit {           /* trace of every finished bit, packet.c:462-463 (tests only) */
+  int sample;
+  float cur_val;
+};
+void orc_pcm_to_real(const int16_t *pcm_be, float *out, int n);                                /* packet.c:340-343 */
+int orc_crc_good(const unsigned char *frame, int length);                                      /* ax25.c:140-156 */
+void orc_afsk_init(struct orc_afsk_state *st);                                                 /* packet.c:410-435 */
+/* packet.c:440-544 over y[0..n): returns the number of frames written to out (at most maxframes; further good frames
+ * are counted in the RTP state but not stored).  bits/maxbits/nbits: optional trace. */
+int orc_afsk_block(struct orc_afsk_state *st, const float complex *y, int n, int sample_base,
+                   struct orc_ax25_frame *out, int maxframes, struct orc_afsk_bit *bits, int maxbits, int *nbits);
+
 /* ---------------------------------------------------------------- misc.c */
 uint32_t orc_nextfastfft(uint32_t n);                                                          /* misc.c:129 */
 

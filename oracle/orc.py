@@ -92,6 +92,23 @@ class PcmState(C.Structure):
                 ("bytes", C.c_longlong), ("samples", C.c_longlong)]
 
 
+class AfskState(C.Structure):  # struct orc_afsk_state
+    _fields_ = [("mark", Osc), ("space", Osc), ("symphase", C.c_int), ("mark_accum", Cf), ("space_accum", Cf),
+                ("mark_offset_accum", Cf), ("space_offset_accum", Cf), ("last_val", C.c_float), ("mid_val", C.c_float),
+                ("hdlc_frame", C.c_ubyte * 1024), ("frame_bit", C.c_int), ("flagsync", C.c_int), ("ones", C.c_int),
+                ("out_timestamp", C.c_uint32), ("out_seq", C.c_uint16), ("out_packets", C.c_longlong),
+                ("out_bytes", C.c_longlong)]
+
+
+class Ax25Frame(C.Structure):  # struct orc_ax25_frame
+    _fields_ = [("sample", C.c_int), ("bytes", C.c_int), ("timestamp", C.c_uint32), ("seq", C.c_uint16),
+                ("data", C.c_ubyte * 1024)]
+
+
+class AfskBit(C.Structure):  # struct orc_afsk_bit
+    _fields_ = [("sample", C.c_int), ("cur_val", C.c_float)]
+
+
 class Notch(C.Structure):
     _fields_ = [("osc_phase", Cd), ("osc_step", Cd), ("dcstate", Cf), ("bw", C.c_float)]
 
@@ -186,6 +203,12 @@ def lib(fast=False):
     L.orc_packetise.argtypes = [vp, vp, i, i, vp, vp, vp, vp, i]
     L.orc_nextfastfft.restype = C.c_uint32
     L.orc_nextfastfft.argtypes = [C.c_uint32]
+    L.orc_pcm_to_real.argtypes = [vp, vp, i]
+    L.orc_pcm_to_real.restype = None
+    L.orc_crc_good.argtypes = [vp, i]
+    L.orc_afsk_init.argtypes = [vp]
+    L.orc_afsk_init.restype = None
+    L.orc_afsk_block.argtypes = [vp, vp, i, i, vp, i, vp, i, vp]
     _libs[path] = L
     return L
 
@@ -214,6 +237,8 @@ def ref(portable=False):
     L.hb15_block.restype = None
     L.hb3_block.argtypes = [vp, vp, vp, i]
     L.hb3_block.restype = None
+    if not portable and hasattr(L, "crc_good"):
+        L.crc_good.argtypes = [vp, i]
     _libs[path] = L
     return L
 
@@ -413,3 +438,51 @@ def new_osc(f, r=0.0, fast=False):
     o = Osc()
     lib(fast).orc_set_osc(C.addressof(o), f, r)
     return o
+
+
+# ---------------------------------------------------------------- packet.c: AFSK-1200 + HDLC per PCM session
+AFSK_L, AFSK_M, AFSK_RATE = 1000, 1049, 48000.0  # packet.c:46-49
+
+
+def crc_good(frame, fast=False):
+    b = np.frombuffer(bytes(frame), np.uint8).copy()
+    return bool(lib(fast).orc_crc_good(_vp(b), b.size))
+
+
+class AfskSession:
+    """One `struct session` of packet.c: big-endian PCM -> REAL filter input (packet.c:325,340-348) -> COMPLEX output,
+    decimate 1, 100 Hz .. 4 kHz (407-408) -> decode_task's loop (437-545)."""
+
+    def __init__(self, fast=False):
+        self.L = lib(fast)
+        self.fin = self.L.orc_create_filter_input(AFSK_L, AFSK_M, REAL)
+        self.fout = self.L.orc_create_filter_output(self.fin, None, 1, COMPLEX)
+        assert self.L.orc_set_filter(self.fout, 100.0 / AFSK_RATE, 4000.0 / AFSK_RATE, 3.0) == 0
+        self.st = AfskState()
+        self.L.orc_afsk_init(C.addressof(self.st))
+        self.consumed = 0
+
+    def block(self, pcm_be, maxframes=16, maxbits=64):
+        """pcm_be: AFSK_L network-order int16 words.  Returns (baseband[AFSK_L], frames, bits)."""
+        pcm_be = np.ascontiguousarray(pcm_be, np.int16)
+        assert pcm_be.size == AFSK_L
+        p = self.L.orc_filter_in_input_r(self.fin)
+        xin = np.frombuffer((C.c_char * (AFSK_L * 4)).from_address(p), np.float32, AFSK_L)
+        self.L.orc_pcm_to_real(_vp(pcm_be), _vp(xin), AFSK_L)
+        self.L.orc_execute_filter_input(self.fin)
+        self.L.orc_execute_filter_output(self.fout, 0)
+        q = self.L.orc_filter_out_output(self.fout)
+        y = np.frombuffer((C.c_char * (AFSK_L * 8)).from_address(q), np.complex64, AFSK_L).copy()
+        frames = (Ax25Frame * maxframes)()
+        bits = (AfskBit * maxbits)()
+        nb = C.c_int(0)
+        nf = self.L.orc_afsk_block(C.addressof(self.st), _vp(y), AFSK_L, self.consumed, frames, maxframes, bits, maxbits,
+                                   C.byref(nb))
+        self.consumed += AFSK_L
+        fr = [dict(sample=f.sample, seq=f.seq, timestamp=f.timestamp, data=bytes(f.data[:f.bytes])) for f in frames[:nf]]
+        bt = [(b.sample, b.cur_val) for b in bits[:min(nb.value, maxbits)]]
+        return y, fr, bt
+
+    def close(self):
+        self.L.orc_delete_filter_output(self.fout)
+        self.L.orc_delete_filter_input(self.fin)

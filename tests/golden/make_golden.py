@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
 """Generates tests/golden/ref_*.npz from the REAL reference objects in oracle/_ref (osc.c, decimate.c, misc.c
+and ax25.c
 compiled unmodified from /root/reference by oracle/Makefile).  Run in the build container only:
 
     make -C oracle && python tests/golden/make_golden.py
@@ -123,6 +124,31 @@ def gen_misc(R):
     return {"n": np.array(ns, np.uint64), "next": np.array([R.nextfastfft(n) for n in ns], np.uint64)}
 
 
+def gen_ax25(R):
+    """crc_good (ax25.c:140-156) on frames with a correct CRC (built by synth.ax25_crc, an independent
+    implementation), frames with one flipped bit, and random bytes."""
+    sys.path.insert(0, os.path.join(ROOT, "ka9q-radio_amd"))
+    import synth
+    R.crc_good.argtypes = [C.c_void_p, C.c_int]
+    rng = np.random.default_rng(0xA25)
+    rows, lens, good = [], [], []
+    for k in range(60):
+        n = int(rng.integers(1, 300))
+        body = rng.integers(0, 256, n, dtype=np.uint8).tobytes()
+        f = bytearray(body + synth.ax25_crc(body))
+        if k % 3 == 1:
+            f[int(rng.integers(0, len(f)))] ^= 1 << int(rng.integers(0, 8))
+        elif k % 3 == 2:
+            f = bytearray(rng.integers(0, 256, n + 2, dtype=np.uint8).tobytes())
+        b = np.frombuffer(bytes(f), np.uint8).copy()
+        row = np.zeros(302, np.uint8)
+        row[:b.size] = b
+        rows.append(row)
+        lens.append(b.size)
+        good.append(int(R.crc_good(b.ctypes.data_as(C.c_void_p), b.size)))
+    return {"data": np.stack(rows), "len": np.array(lens, np.int64), "good": np.array(good, np.int64)}
+
+
 def main():
     R = orc.ref()
     Rp = orc.ref(portable=True)
@@ -133,7 +159,8 @@ def main():
     d.update(gen_decimate(Rp, "portable"))
     np.savez_compressed(os.path.join(HERE, "ref_decimate.npz"), **d)
     np.savez_compressed(os.path.join(HERE, "ref_misc.npz"), **gen_misc(R))
-    for f in ("ref_osc.npz", "ref_decimate.npz", "ref_misc.npz"):
+    np.savez_compressed(os.path.join(HERE, "ref_ax25.npz"), **gen_ax25(R))
+    for f in ("ref_osc.npz", "ref_decimate.npz", "ref_misc.npz", "ref_ax25.npz"):
         print(f, os.path.getsize(os.path.join(HERE, f)), "bytes")
 
 
