@@ -249,6 +249,51 @@ int kh_bank_rtp_set_state(kh_bank *, unsigned int ch, const struct kh_rtp_state 
  * without demodulator); *after = state after the last chunk.  Synchronises. */
 int kh_bank_read_rtp(kh_bank *, unsigned int ch, struct kh_rtp_chunk *out, size_t max_chunks, size_t *nchunks,
                      struct kh_rtp_state *after);
+/* ---- packet.c's receive side: AFSK-1200 demodulator + HDLC + CRC for many PCM sessions at once.
+ * The reference gives every RTP session (ssrc) a REAL filter_in (L = 1000, M = 1049 -> N = 2048), a COMPLEX
+ * filter_out (decimate 1, 100 Hz .. 4 kHz, beta 3) and a decode thread (packet.c:315-326, 402-408); this object is
+ * that, `sessions` times over, with all sessions advanced together by kh_afsk_execute.  Input is what `packet`
+ * takes from the network: 48 kS/s mono PCM in network byte order (packet.c:312,340-343), e.g. straight from
+ * kh_bank_pcm_device_ptr of a bank whose FM channels run at 48 kS/s. */
+#define KH_AFSK_L 1000   /* packet.c:46 */
+#define KH_AFSK_M 1049   /* packet.c:48 */
+#define KH_AX25_MAX 1024 /* packet.c:431: hdlc_frame[1024]; the reference has no bound check, longer frames are dropped here */
+typedef struct kh_afsk kh_afsk;
+struct kh_ax25_frame {   /* a frame that passed crc_good (packet.c:477), as packet.c:494-509 hands it to send() */
+  uint64_t sample;       /* samples consumed by the session up to and including the one that closed the frame */
+  uint32_t timestamp;    /* RTP header fields of the AX25_PT packet, packet.c:498-502 */
+  uint16_t seq;
+  uint16_t bytes;        /* length including the two CRC bytes */
+  uint8_t data[KH_AX25_MAX];
+};
+struct kh_afsk_bit {     /* trace of every finished bit (packet.c:462-463); for tests */
+  uint64_t sample;
+  float cur_val;
+  uint32_t reserved;
+};
+struct kh_afsk_status {  /* sp->rtp_state_out and the HDLC state after the last launch */
+  uint32_t timestamp;
+  uint16_t seq;
+  uint16_t flagsync;
+  uint64_t packets, bytes;
+  uint32_t frames_last_launch; /* good frames of the last launch (may exceed what max_frames kept) */
+  uint32_t bits_last_launch;
+};
+kh_afsk *kh_afsk_create(unsigned int sessions, unsigned int max_blocks, unsigned int max_frames, unsigned int max_bits);
+int kh_afsk_destroy(kh_afsk *); /* NULL -> 0 */
+/* nwords network-order int16 words appended to the session's pending input (host memory) */
+int kh_afsk_write_pcm(kh_afsk *, unsigned int session, const int16_t *pcm_be, size_t nwords);
+/* device-resident producers: row `session` of the pending-input array starts at dptr + session*stride_words */
+int kh_afsk_pcm_device_ptr(kh_afsk *, void **dptr, size_t *stride_words);
+int kh_afsk_commit_pcm(kh_afsk *, unsigned int session, size_t nwords);
+/* consumes nblocks*KH_AFSK_L words of every session (all must have them); asynchronous like kh_bank_execute */
+int kh_afsk_execute(kh_afsk *, unsigned int nblocks);
+int kh_afsk_sync(kh_afsk *);
+int kh_afsk_read_frames(kh_afsk *, unsigned int session, struct kh_ax25_frame *out, size_t max, size_t *n);
+int kh_afsk_read_bits(kh_afsk *, unsigned int session, struct kh_afsk_bit *out, size_t max, size_t *n);
+int kh_afsk_read_status(kh_afsk *, unsigned int session, struct kh_afsk_status *out);
+int kh_afsk_read_baseband(kh_afsk *, unsigned int session, kh_cf32 *out, size_t nsamples); /* analytic signal, last launch */
+
 void *kh_bank_stream(kh_bank *); /* hipStream_t */
 /* per-kernel timing with HIP events on the bank's stream.  Stages: */
 enum kh_stage { KH_STAGE_INGEST = 0, KH_STAGE_FFT1, KH_STAGE_FFT2, KH_STAGE_N0, KH_STAGE_CHAN, KH_STAGE_DEMOD,

@@ -207,4 +207,22 @@ int launch_decimate(hipStream_t st, float *rails, size_t rail_stride, int nrails
 // copy count elements of elem_bytes from src to dst for each of n rows (overlap-save history carry, filter.c:230)
 int launch_carry(hipStream_t st, const void *src, void *dst, size_t row_stride_bytes, size_t bytes, int nrows);
 
+// ---------------------------------------------------------------- packet.c (kh_packet_kernels.hip, kh_packet.cpp)
+struct AfskState { // the locals of decode_task (packet.c:410-435) and sp->rtp_state_out, one per session
+  double mark_re, mark_im, space_re, space_im; // oscillator phasors (steps are launch constants)
+  int mark_steps, space_steps;
+  int symphase;
+  float2 mark_acc, space_acc, mark_off, space_off;
+  float last_val, mid_val;
+  int frame_bit, flagsync, ones;
+  unsigned out_timestamp, out_seq;
+  unsigned long long out_packets, out_bytes;
+  unsigned char hdlc_frame[1024];
+};
+int launch_afsk_ingest(hipStream_t st, const void *pcm_be, size_t pcm_stride, float *time, size_t time_stride, int hist,
+                       int count, int nsess);
+int launch_afsk_decode(hipStream_t st, const float2 *y, size_t y_stride, int nsamp, int nsess, AfskState *states,
+                       void *frames, int max_frames, int *nframes, void *bits, int max_bits, int *nbits,
+                       unsigned long long sample_base);
+
 } // namespace kh

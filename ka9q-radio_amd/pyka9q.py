@@ -29,6 +29,9 @@ EXPORTS = [
     "kh_bank_read_status", "kh_bank_read_input_status", "kh_bank_read_spectrum", "kh_bank_read_response",
     "kh_bank_pcm_device_ptr", "kh_bank_keep_audio", "kh_bank_keep_baseband", "kh_bank_use_graph", "kh_bank_stream", "kh_bank_profile", "kh_bank_stage_times",
     "kh_stage_kernel_name", "kh_bank_rtp_enable", "kh_bank_rtp_set_state", "kh_bank_read_rtp",
+    "kh_afsk_create", "kh_afsk_destroy", "kh_afsk_write_pcm", "kh_afsk_pcm_device_ptr", "kh_afsk_commit_pcm",
+    "kh_afsk_execute", "kh_afsk_sync", "kh_afsk_read_frames", "kh_afsk_read_bits", "kh_afsk_read_status",
+    "kh_afsk_read_baseband",
 ]
 
 
@@ -156,6 +159,18 @@ def lib():
     L.kh_bank_stage_times.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_uint)]
     L.kh_stage_kernel_name.restype = C.c_char_p
     L.kh_stage_kernel_name.argtypes = [C.c_int]
+    L.kh_afsk_create.restype = C.c_void_p
+    L.kh_afsk_create.argtypes = [C.c_uint, C.c_uint, C.c_uint, C.c_uint]
+    L.kh_afsk_destroy.argtypes = [C.c_void_p]
+    L.kh_afsk_write_pcm.argtypes = [C.c_void_p, C.c_uint, C.c_void_p, C.c_size_t]
+    L.kh_afsk_pcm_device_ptr.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]
+    L.kh_afsk_commit_pcm.argtypes = [C.c_void_p, C.c_uint, C.c_size_t]
+    L.kh_afsk_execute.argtypes = [C.c_void_p, C.c_uint]
+    L.kh_afsk_sync.argtypes = [C.c_void_p]
+    L.kh_afsk_read_frames.argtypes = [C.c_void_p, C.c_uint, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]
+    L.kh_afsk_read_bits.argtypes = [C.c_void_p, C.c_uint, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]
+    L.kh_afsk_read_status.argtypes = [C.c_void_p, C.c_uint, C.c_void_p]
+    L.kh_afsk_read_baseband.argtypes = [C.c_void_p, C.c_uint, C.c_void_p, C.c_size_t]
     _lib = L
     return L
 
@@ -407,3 +422,67 @@ class Bank:
             self.close()
         except Exception:
             pass
+
+
+class Afsk:
+    """packet.c's receive side for `sessions` PCM streams (kh_afsk_*): AFSK-1200 + HDLC + CRC on the device."""
+    L, M = 1000, 1049
+    FRAME = np.dtype([("sample", "<u8"), ("timestamp", "<u4"), ("seq", "<u2"), ("bytes", "<u2"), ("data", "u1", (1024,))])
+    BIT = np.dtype([("sample", "<u8"), ("cur_val", "<f4"), ("reserved", "<u4")])
+    STATUS = np.dtype([("timestamp", "<u4"), ("seq", "<u2"), ("flagsync", "<u2"), ("packets", "<u8"), ("bytes", "<u8"),
+                       ("frames_last_launch", "<u4"), ("bits_last_launch", "<u4")])
+
+    def __init__(self, sessions, max_blocks, max_frames=16, max_bits=0):
+        self.lib = lib()
+        self.S, self.T, self.max_frames, self.max_bits = sessions, max_blocks, max_frames, max_bits
+        self.h = self.lib.kh_afsk_create(sessions, max_blocks, max_frames, max_bits)
+        if not self.h:
+            raise RuntimeError("kh_afsk_create: " + last_error())
+
+    def write_pcm(self, session, pcm_be):
+        pcm_be = np.ascontiguousarray(pcm_be, np.int16)
+        _check(self.lib.kh_afsk_write_pcm(self.h, session, pcm_be.ctypes.data, pcm_be.size), "kh_afsk_write_pcm")
+
+    def pcm_device_ptr(self):
+        p, st = C.c_void_p(), C.c_size_t()
+        _check(self.lib.kh_afsk_pcm_device_ptr(self.h, C.byref(p), C.byref(st)), "kh_afsk_pcm_device_ptr")
+        return p.value, st.value
+
+    def commit_pcm(self, session, nwords):
+        _check(self.lib.kh_afsk_commit_pcm(self.h, session, nwords), "kh_afsk_commit_pcm")
+
+    def execute(self, nblocks, sync=True):
+        _check(self.lib.kh_afsk_execute(self.h, nblocks), "kh_afsk_execute")
+        if sync:
+            self.sync()
+
+    def sync(self):
+        _check(self.lib.kh_afsk_sync(self.h), "kh_afsk_sync")
+
+    def frames(self, session):
+        out = np.zeros(self.max_frames, self.FRAME)
+        n = C.c_size_t()
+        _check(self.lib.kh_afsk_read_frames(self.h, session, out.ctypes.data, self.max_frames, C.byref(n)), "kh_afsk_read_frames")
+        return [dict(sample=int(f["sample"]), seq=int(f["seq"]), timestamp=int(f["timestamp"]),
+                     data=bytes(f["data"][:f["bytes"]])) for f in out[:n.value]]
+
+    def bits(self, session):
+        out = np.zeros(max(self.max_bits, 1), self.BIT)
+        n = C.c_size_t()
+        _check(self.lib.kh_afsk_read_bits(self.h, session, out.ctypes.data, self.max_bits, C.byref(n)), "kh_afsk_read_bits")
+        return out[:n.value]
+
+    def status(self, session):
+        out = np.zeros(1, self.STATUS)
+        _check(self.lib.kh_afsk_read_status(self.h, session, out.ctypes.data), "kh_afsk_read_status")
+        return out[0]
+
+    def baseband(self, session, nblocks):
+        out = np.empty(nblocks * self.L, np.complex64)
+        _check(self.lib.kh_afsk_read_baseband(self.h, session, out.ctypes.data, out.size), "kh_afsk_read_baseband")
+        return out
+
+    def close(self):
+        if self.h:
+            self.lib.kh_afsk_destroy(self.h)
+            self.h = None
