@@ -294,6 +294,35 @@ int kh_afsk_read_bits(kh_afsk *, unsigned int session, struct kh_afsk_bit *out, 
 int kh_afsk_read_status(kh_afsk *, unsigned int session, struct kh_afsk_status *out);
 int kh_afsk_read_baseband(kh_afsk *, unsigned int session, kh_cf32 *out, size_t nsamples); /* analytic signal, last launch */
 
+/* ---- pl.c: CTCSS ("PL") tone and DTMF decoders for many 48 kS/s mono PCM sessions.
+ * The reference steps 55 + 8 tone oscillators per audio sample per session and looks at the integrators every 250 ms
+ * (PL, pl.c:26,255,360-387) and 50 ms (DTMF, pl.c:27,270,390-439).  A launch takes a whole number of 50 ms intervals
+ * (KH_DTMF_BLOCK samples) from every session; PL intervals may straddle launches. */
+#define KH_PL_NTONES 55    /* pl.c:36-46 */
+#define KH_PL_BLOCK 12000  /* pl.c:26 */
+#define KH_DTMF_BLOCK 2400 /* pl.c:27 */
+typedef struct kh_tones kh_tones;
+struct kh_pl_result {   /* process_pl, pl.c:360-387 */
+  float tone;           /* Hz; 0: the strongest correlator is less than 6 dB above the next */
+  float snr;            /* dB between the two */
+  float e0, e1;         /* their energies */
+  int32_t index;        /* of the strongest, into PL_tones (pl.c:36-44) */
+};
+struct kh_dtmf_result { /* process_dtmf, pl.c:390-439 */
+  int32_t digit;        /* character; 0: none */
+  int32_t low_index, high_index; /* -1: below 10 (pl.c:408,426) */
+  float low_snr, high_snr;
+};
+kh_tones *kh_tones_create(unsigned int sessions, unsigned int max_windows /* 50 ms intervals per launch */);
+int kh_tones_destroy(kh_tones *); /* NULL -> 0 */
+int kh_tones_write_pcm(kh_tones *, unsigned int session, const int16_t *pcm_be, size_t nwords);
+int kh_tones_pcm_device_ptr(kh_tones *, void **dptr, size_t *stride_words);
+int kh_tones_commit_pcm(kh_tones *, unsigned int session, size_t nwords);
+int kh_tones_execute(kh_tones *, unsigned int nwindows); /* takes nwindows*KH_DTMF_BLOCK words of every session */
+int kh_tones_sync(kh_tones *);
+int kh_tones_read_pl(kh_tones *, unsigned int session, struct kh_pl_result *out, size_t max, size_t *n);
+int kh_tones_read_dtmf(kh_tones *, unsigned int session, struct kh_dtmf_result *out, size_t max, size_t *n);
+
 void *kh_bank_stream(kh_bank *); /* hipStream_t */
 /* per-kernel timing with HIP events on the bank's stream.  Stages: */
 enum kh_stage { KH_STAGE_INGEST = 0, KH_STAGE_FFT1, KH_STAGE_FFT2, KH_STAGE_N0, KH_STAGE_CHAN, KH_STAGE_DEMOD,

@@ -225,4 +225,19 @@ int launch_afsk_decode(hipStream_t st, const float2 *y, size_t y_stride, int nsa
                        void *frames, int max_frames, int *nframes, void *bits, int max_bits, int *nbits,
                        unsigned long long sample_base);
 
+// pl.c: tone tables and per-session carry between launches
+struct ToneTable {
+  double freq[64];   // cycles/sample as set_osc receives them (pl.c:320,327-328): 55 PL, 4 DTMF low, 4 DTMF high
+  double rate[64];   // effective sweep in cycles/sample^2 (pl.c:320 passes 9: arg(cispi(18)) / 2 pi)
+  float tone_hz[64]; // PL_tones, pl.c:36-44
+};
+struct TonesState {
+  double2 pl_part[55]; // PL integrators of the 50 ms intervals seen so far in the running 250 ms interval
+  int pl_windows;      // how many of them (0..4)
+  int pad;
+};
+int launch_tones(hipStream_t st, const void *pcm_be, size_t pcm_stride, const ToneTable *tab, void *part, int max_windows,
+                 int nwindows, int nsess, TonesState *states, void *pl, int max_pl, int *npl, void *dt,
+                 unsigned long long base);
+
 } // namespace kh

@@ -7,6 +7,7 @@
 //   AFSK correlators, Gardner timing, HDLC, CRC     packet.c:440-544       kh_afsk_decode
 // All state (overlap history, tone oscillators, bit clock, partial frame, RTP counters) stays on the device.
 #include <hip/hip_runtime.h>
+#include <algorithm>
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
@@ -262,6 +263,190 @@ int kh_afsk_read_baseband(kh_afsk *a, unsigned int session, kh_cf32 *out, size_t
                              a->stream)) ||
       !KH_HIP(hipStreamSynchronize(a->stream)))
     return -1;
+  return 0;
+}
+
+} // extern "C"
+
+// ================================================================ pl.c: CTCSS and DTMF decoders
+struct kh_tones {
+  int S = 0, W = 0, max_pl = 0;
+  hipStream_t stream = nullptr;
+  uint16_t *d_pcm = nullptr; // [S][W*2400] pending input, network order
+  double2 *d_part = nullptr; // [S][W][63]
+  ToneTable *d_tab = nullptr;
+  TonesState *d_state = nullptr;
+  kh_pl_result *d_pl = nullptr;     // [S][max_pl]
+  kh_dtmf_result *d_dtmf = nullptr; // [S][W]
+  int *d_npl = nullptr;
+  size_t pcm_stride = 0;
+  unsigned last_windows = 0;
+  unsigned long long consumed = 0;
+  std::vector<size_t> fill;
+};
+
+extern "C" {
+
+int kh_tones_destroy(kh_tones *a) {
+  if (!a) return 0;
+  if (a->stream) hipStreamSynchronize(a->stream);
+  void *ptrs[] = {a->d_pcm, a->d_part, a->d_tab, a->d_state, a->d_pl, a->d_dtmf, a->d_npl};
+  for (void *p : ptrs)
+    if (p) hipFree(p);
+  if (a->stream) hipStreamDestroy(a->stream);
+  delete a;
+  return 0;
+}
+
+kh_tones *kh_tones_create(unsigned int sessions, unsigned int max_windows) {
+  if (ensure_init()) return nullptr;
+  if (sessions == 0 || max_windows == 0 || sessions > (1u << 20) || max_windows > 4096) {
+    set_error("kh_tones_create: sessions in [1, 2^20] and max_windows in [1, 4096] are required");
+    return nullptr;
+  }
+  static const float PL_tones[KH_PL_NTONES] = { // pl.c:36-44
+      67.0,  69.3,  71.9,  74.4,  77.0,  79.7,  82.5,  85.4,  88.5,  91.5,  94.8,  97.4,
+      100.0, 103.5, 107.2, 110.9, 114.8, 118.8, 123.0, 127.3, 131.8, 136.5, 141.3, 146.2,
+      150.0, 151.4, 156.7, 162.2, 167.9, 173.8, 179.9, 186.2, 192.8, 199.5, 206.5, 213.8,
+      221.3, 229.1, 237.1, 245.5, 254.1, 159.8, 165.5, 171.3, 177.3, 183.5, 189.9, 196.6,
+      203.5, 210.7, 218.1, 225.7, 233.6, 241.8, 250.3,
+  };
+  static const float DTMF_low[4] = {697, 770, 852, 941}, DTMF_high[4] = {1209, 1336, 1477, 1633}; // pl.c:48-49
+  kh_tones *a = new kh_tones();
+  a->S = (int)sessions;
+  a->W = (int)max_windows;
+  a->max_pl = (int)max_windows / (KH_PL_BLOCK / KH_DTMF_BLOCK) + 1;
+  size_t const S = sessions, W = max_windows;
+  a->pcm_stride = W * KH_DTMF_BLOCK;
+  bool ok = KH_HIP(hipStreamCreateWithFlags(&a->stream, hipStreamNonBlocking));
+  auto A = [&](auto **p, size_t bytes) {
+    if (!ok) return;
+    ok = KH_HIP(hipMalloc((void **)p, bytes ? bytes : 16));
+    if (ok) ok = KH_HIP(hipMemset(*p, 0, bytes ? bytes : 16));
+  };
+  A(&a->d_pcm, S * a->pcm_stride * sizeof(uint16_t));
+  A(&a->d_part, S * W * (KH_PL_NTONES + 8) * sizeof(double2));
+  A(&a->d_tab, sizeof(ToneTable));
+  A(&a->d_state, S * sizeof(TonesState));
+  A(&a->d_pl, S * (size_t)a->max_pl * sizeof(kh_pl_result));
+  A(&a->d_dtmf, S * W * sizeof(kh_dtmf_result));
+  A(&a->d_npl, S * sizeof(int));
+  if (ok) {
+    ToneTable t;
+    memset(&t, 0, sizeof t);
+    int const SAMPRATE = 48000; // pl.c:25
+    // set_osc(&pl_osc[n], PL_tones[n]/SAMPRATE, 9), pl.c:320: a float quotient; the "rate" of 9 cycles/sample^2 leaves
+    // phasor_step_step = cispi(18) (osc.c:32), i.e. a sweep of arg(cispi(18)) / 2 pi cycles/sample^2
+    double const sweep = atan2(sin(18 * M_PI), cos(18 * M_PI)) / (2 * M_PI);
+    for (int n = 0; n < KH_PL_NTONES; n++) {
+      t.freq[n] = (double)(PL_tones[n] / SAMPRATE);
+      t.rate[n] = sweep;
+      t.tone_hz[n] = PL_tones[n];
+    }
+    for (int n = 0; n < 4; n++) { // pl.c:327-328
+      t.freq[KH_PL_NTONES + n] = (double)(DTMF_low[n] / SAMPRATE);
+      t.freq[KH_PL_NTONES + 4 + n] = (double)(DTMF_high[n] / SAMPRATE);
+    }
+    ok = KH_HIP(hipMemcpy(a->d_tab, &t, sizeof t, hipMemcpyHostToDevice));
+  }
+  if (!ok) {
+    kh_tones_destroy(a);
+    return nullptr;
+  }
+  a->fill.assign(S, 0);
+  return a;
+}
+
+static bool tsession_ok(kh_tones *a, unsigned int session, const char *who) {
+  if (!a || session >= (unsigned)a->S) {
+    set_error("%s: bad handle or session", who);
+    return false;
+  }
+  return true;
+}
+
+int kh_tones_write_pcm(kh_tones *a, unsigned int session, const int16_t *pcm_be, size_t nwords) {
+  if (!tsession_ok(a, session, "kh_tones_write_pcm") || (!pcm_be && nwords)) return -1;
+  size_t &f = a->fill[session];
+  if (f + nwords > a->pcm_stride) {
+    set_error("kh_tones_write_pcm: %zu pending + %zu new words exceed max_windows * %d", f, nwords, KH_DTMF_BLOCK);
+    return -1;
+  }
+  if (!KH_HIP(hipMemcpyAsync(a->d_pcm + session * a->pcm_stride + f, pcm_be, nwords * sizeof(int16_t),
+                             hipMemcpyHostToDevice, a->stream)))
+    return -1;
+  f += nwords;
+  return 0;
+}
+
+int kh_tones_pcm_device_ptr(kh_tones *a, void **dptr, size_t *stride_words) {
+  if (!a || !dptr) return -1;
+  *dptr = a->d_pcm;
+  if (stride_words) *stride_words = a->pcm_stride;
+  return 0;
+}
+
+int kh_tones_commit_pcm(kh_tones *a, unsigned int session, size_t nwords) {
+  if (!tsession_ok(a, session, "kh_tones_commit_pcm")) return -1;
+  if (a->fill[session] + nwords > a->pcm_stride) {
+    set_error("kh_tones_commit_pcm: more than max_windows * %d words pending", KH_DTMF_BLOCK);
+    return -1;
+  }
+  a->fill[session] += nwords;
+  return 0;
+}
+
+int kh_tones_execute(kh_tones *a, unsigned int nwindows) {
+  if (!a || nwindows == 0 || nwindows > (unsigned)a->W) {
+    set_error("kh_tones_execute: nwindows must be in [1, max_windows]");
+    return -1;
+  }
+  size_t const need = (size_t)nwindows * KH_DTMF_BLOCK;
+  for (int s = 0; s < a->S; s++)
+    if (a->fill[s] != need) {
+      set_error("kh_tones_execute: session %d holds %zu words, the launch takes exactly %zu from every session", s,
+                a->fill[s], need);
+      return -1;
+    }
+  if (launch_tones(a->stream, a->d_pcm, a->pcm_stride, a->d_tab, a->d_part, a->W, (int)nwindows, a->S, a->d_state, a->d_pl,
+                   a->max_pl, a->d_npl, a->d_dtmf, a->consumed))
+    return -1;
+  a->consumed += need;
+  a->last_windows = nwindows;
+  for (auto &f : a->fill) f = 0;
+  return 0;
+}
+
+int kh_tones_sync(kh_tones *a) {
+  if (!a) return -1;
+  return KH_HIP(hipStreamSynchronize(a->stream)) ? 0 : -1;
+}
+
+int kh_tones_read_pl(kh_tones *a, unsigned int session, struct kh_pl_result *out, size_t max, size_t *n) {
+  if (!tsession_ok(a, session, "kh_tones_read_pl") || !n) return -1;
+  int cnt = 0;
+  if (!KH_HIP(hipMemcpyAsync(&cnt, a->d_npl + session, sizeof(int), hipMemcpyDeviceToHost, a->stream)) ||
+      !KH_HIP(hipStreamSynchronize(a->stream)))
+    return -1;
+  size_t const take = std::min(std::min((size_t)cnt, (size_t)a->max_pl), max);
+  if (take && out &&
+      (!KH_HIP(hipMemcpyAsync(out, a->d_pl + (size_t)session * a->max_pl, take * sizeof(kh_pl_result), hipMemcpyDeviceToHost,
+                              a->stream)) ||
+       !KH_HIP(hipStreamSynchronize(a->stream))))
+    return -1;
+  *n = take;
+  return 0;
+}
+
+int kh_tones_read_dtmf(kh_tones *a, unsigned int session, struct kh_dtmf_result *out, size_t max, size_t *n) {
+  if (!tsession_ok(a, session, "kh_tones_read_dtmf") || !n) return -1;
+  size_t const take = std::min((size_t)a->last_windows, max);
+  if (take && out &&
+      (!KH_HIP(hipMemcpyAsync(out, a->d_dtmf + (size_t)session * a->W, take * sizeof(kh_dtmf_result), hipMemcpyDeviceToHost,
+                              a->stream)) ||
+       !KH_HIP(hipStreamSynchronize(a->stream))))
+    return -1;
+  *n = take;
   return 0;
 }
 

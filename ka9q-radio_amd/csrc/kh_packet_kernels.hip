@@ -3,7 +3,9 @@
 //                                       overlap-save time buffer of every session
 //   kh_afsk_decode   packet.c:437-545   mark/space correlators, Gardner timing, NRZI, HDLC unstuffing, crc_good
 //                                       (ax25.c:140-156); one lane per session
-// The REAL -> COMPLEX analytic filter between the two (packet.c:325,407-408: L = 1000, M = 1049, N = 2048, decimate 1,
+//   kh_tones_corr    pl.c:248-269       55 CTCSS + 8 DTMF tone correlators over one 50 ms interval per workgroup
+//   kh_tones_decide  pl.c:360-439       process_pl / process_dtmf per session
+// The REAL -> COMPLEX analytic filter between the first two (packet.c:325,407-408: L = 1000, M = 1049, N = 2048, decimate 1,
 // 100 Hz .. 4 kHz, beta 3) is the library's own forward transform and filter-output kernel.
 #include <hip/hip_runtime.h>
 #include <math.h>
@@ -197,6 +199,148 @@ int launch_afsk_decode(hipStream_t st, const float2 *y, size_t y_stride, int nsa
   hipLaunchKernelGGL(kh_afsk_decode, dim3((nsess + 63) / 64), dim3(64), 0, st, y, y_stride, nsamp, nsess, states,
                      static_cast<kh_ax25_frame *>(frames), max_frames, nframes, static_cast<kh_afsk_bit *>(bits), max_bits,
                      nbits, msre, msim, ssre, ssim, sample_base);
+  return KH_HIP(hipGetLastError()) ? 0 : -1;
+}
+
+// ================================================================ pl.c: CTCSS ("PL") and DTMF correlator banks
+// pl.c:249-269 runs 63 oscillators per audio sample and adds samp * phasor to 63 integrators; the integration
+// intervals are fixed (12000 samples for PL, 2400 for DTMF, pl.c:26-27), so every interval is an independent sum.
+// One workgroup per (DTMF interval, session): the 2400 samples sit in LDS, thread (tone, quarter) runs 600 of them
+// with the oscillator started in closed form (step_osc returns prod_{k<=n} step_k with step_k = step_0 ss^k:
+// phase(n) = n f + r n(n+1)/2 cycles; r is what is left of pl.c:320's sweep rate 9 after cispi(18) ~ 1 - 2.2e-15 i)
+// and stepped in fp64, and the four quarters are added in a fixed order.  A PL interval is five such sums, added by
+// kh_tones_decide.  algorithmic bytes: 2 per sample.
+constexpr int TONES_W = 2400, TONES_Q = 4, TONES_N = KH_PL_NTONES + 8;
+__global__ __launch_bounds__(256) void kh_tones_corr(const uint16_t *__restrict__ pcm, size_t pcm_stride,
+                                                     const ToneTable *__restrict__ tab, double2 *__restrict__ part,
+                                                     int max_windows, unsigned long long base) {
+  __shared__ float x[TONES_W];
+  __shared__ double2 acc[TONES_N * TONES_Q];
+  int const w = blockIdx.x, s = blockIdx.y, tid = threadIdx.x;
+  const uint16_t *src = pcm + (size_t)s * pcm_stride + (size_t)w * TONES_W;
+  for (int n = tid; n < TONES_W; n += 256) {
+    uint16_t const v = src[n];
+    short const host = (short)(uint16_t)((v << 8) | (v >> 8)); // (short)ntohs(), pl.c:251
+    x[n] = (1.f / 32767) * (float)host;                        // SCALE16 = 1./SHRT_MAX, pl.c:29
+  }
+  __syncthreads();
+  if (tid < TONES_N * TONES_Q) {
+    int const t = tid / TONES_Q, q = tid % TONES_Q;
+    constexpr int CH = TONES_W / TONES_Q;
+    double const f = tab->freq[t], r = tab->rate[t];
+    unsigned long long const n0 = base + (unsigned long long)w * TONES_W + (unsigned)(q * CH);
+    double const dn = (double)n0;
+    double ph = dn * f;
+    ph -= floor(ph);
+    ph += r * (0.5 * dn * (dn + 1.0)); // |r| ~ 3.5e-16: far below one cycle for any run length of interest
+    double pre, pim, sre, sim;
+    sincospi(2.0 * ph, &pim, &pre);
+    sincospi(2.0 * (f + r * (dn + 0.5 * CH)), &sim, &sre);
+    double are = 0.0, aim = 0.0;
+    const float *xs = x + q * CH;
+    for (int n = 0; n < CH; n++) {
+      double const v = (double)xs[n];
+      are = fma(v, pre, are);
+      aim = fma(v, pim, aim);
+      double const nre = pre * sre - pim * sim;
+      pim = pre * sim + pim * sre;
+      pre = nre;
+    }
+    acc[tid] = make_double2(are, aim);
+  }
+  __syncthreads();
+  if (tid < TONES_N) {
+    double2 a = acc[tid * TONES_Q];
+#pragma unroll
+    for (int q = 1; q < TONES_Q; q++) {
+      a.x += acc[tid * TONES_Q + q].x;
+      a.y += acc[tid * TONES_Q + q].y;
+    }
+    part[((size_t)s * max_windows + w) * TONES_N + tid] = a;
+  }
+}
+
+__device__ __forceinline__ int dtmf_group_dev(const double2 *p, float *snr_out) { // pl.c:395-410
+  int index = -1;
+  float max_energy = 0.f, total_energy = 0.f;
+  for (int n = 0; n < 4; n++) {
+    float const re = (float)p[n].x, im = (float)p[n].y; // the integrators are complex float
+    float const energy = re * re + im * im;
+    total_energy += energy;
+    if (energy >= max_energy) {
+      max_energy = energy;
+      index = n;
+    }
+  }
+  float const snr = max_energy / (total_energy - max_energy);
+  if (snr < 10) index = -1; // (NaN from digital silence does not take this branch: quirk kept)
+  *snr_out = snr;
+  return index;
+}
+
+// one lane per session; the launch's intervals in order
+__global__ __launch_bounds__(64) void kh_tones_decide(const double2 *__restrict__ part, int max_windows, int nwindows,
+                                                      int nsess, const ToneTable *__restrict__ tab,
+                                                      TonesState *__restrict__ states, kh_pl_result *__restrict__ pl,
+                                                      int max_pl, int *__restrict__ npl, kh_dtmf_result *__restrict__ dt) {
+  int const s = blockIdx.x * 64 + threadIdx.x;
+  if (s >= nsess) return;
+  TonesState *st = states + s;
+  int done = st->pl_windows;
+  int np = 0;
+  for (int w = 0; w < nwindows; w++) {
+    const double2 *p = part + ((size_t)s * max_windows + w) * TONES_N;
+    for (int t = 0; t < KH_PL_NTONES; t++) {
+      st->pl_part[t].x += p[t].x;
+      st->pl_part[t].y += p[t].y;
+    }
+    if (++done == KH_PL_BLOCK / TONES_W) { // process_pl, pl.c:360-387
+      done = 0;
+      float e0 = -1.f, e1 = -1.f;
+      int i0 = 0;
+      for (int t = 0; t < KH_PL_NTONES; t++) {
+        float const re = (float)st->pl_part[t].x, im = (float)st->pl_part[t].y;
+        float const e = re * re + im * im;
+        st->pl_part[t] = make_double2(0.0, 0.0);
+        if (e > e0) {
+          e1 = e0;
+          e0 = e;
+          i0 = t;
+        } else if (e > e1)
+          e1 = e;
+      }
+      float const snr = 10.f * log10f(e0) - 10.f * log10f(e1); // power2dB, dsp.h:74
+      if (np < max_pl) {
+        kh_pl_result r;
+        r.tone = snr >= 6 ? tab->tone_hz[i0] : 0.f;
+        r.snr = snr;
+        r.e0 = e0;
+        r.e1 = e1;
+        r.index = i0;
+        pl[(size_t)s * max_pl + np] = r;
+      }
+      np++;
+    }
+    kh_dtmf_result d; // process_dtmf, pl.c:390-439
+    d.low_index = dtmf_group_dev(p + KH_PL_NTONES, &d.low_snr);
+    d.high_index = dtmf_group_dev(p + KH_PL_NTONES + 4, &d.high_snr);
+    const char matrix[17] = "123A456B789C*0#D";
+    d.digit = (d.low_index != -1 && d.high_index != -1) ? matrix[d.low_index * 4 + d.high_index] : 0;
+    dt[(size_t)s * max_windows + w] = d;
+  }
+  st->pl_windows = done;
+  npl[s] = np;
+}
+
+int launch_tones(hipStream_t st, const void *pcm, size_t pcm_stride, const ToneTable *tab, void *part, int max_windows,
+                 int nwindows, int nsess, TonesState *states, void *pl, int max_pl, int *npl, void *dt,
+                 unsigned long long base) {
+  if (nwindows <= 0 || nsess <= 0) return 0;
+  hipLaunchKernelGGL(kh_tones_corr, dim3(nwindows, nsess), dim3(256), 0, st, static_cast<const uint16_t *>(pcm), pcm_stride,
+                     tab, static_cast<double2 *>(part), max_windows, base);
+  hipLaunchKernelGGL(kh_tones_decide, dim3((nsess + 63) / 64), dim3(64), 0, st, static_cast<const double2 *>(part),
+                     max_windows, nwindows, nsess, tab, states, static_cast<kh_pl_result *>(pl), max_pl, npl,
+                     static_cast<kh_dtmf_result *>(dt));
   return KH_HIP(hipGetLastError()) ? 0 : -1;
 }
 

@@ -32,6 +32,8 @@ EXPORTS = [
     "kh_afsk_create", "kh_afsk_destroy", "kh_afsk_write_pcm", "kh_afsk_pcm_device_ptr", "kh_afsk_commit_pcm",
     "kh_afsk_execute", "kh_afsk_sync", "kh_afsk_read_frames", "kh_afsk_read_bits", "kh_afsk_read_status",
     "kh_afsk_read_baseband",
+    "kh_tones_create", "kh_tones_destroy", "kh_tones_write_pcm", "kh_tones_pcm_device_ptr", "kh_tones_commit_pcm",
+    "kh_tones_execute", "kh_tones_sync", "kh_tones_read_pl", "kh_tones_read_dtmf",
 ]
 
 
@@ -171,6 +173,16 @@ def lib():
     L.kh_afsk_read_bits.argtypes = [C.c_void_p, C.c_uint, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]
     L.kh_afsk_read_status.argtypes = [C.c_void_p, C.c_uint, C.c_void_p]
     L.kh_afsk_read_baseband.argtypes = [C.c_void_p, C.c_uint, C.c_void_p, C.c_size_t]
+    L.kh_tones_create.restype = C.c_void_p
+    L.kh_tones_create.argtypes = [C.c_uint, C.c_uint]
+    L.kh_tones_destroy.argtypes = [C.c_void_p]
+    L.kh_tones_write_pcm.argtypes = [C.c_void_p, C.c_uint, C.c_void_p, C.c_size_t]
+    L.kh_tones_pcm_device_ptr.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]
+    L.kh_tones_commit_pcm.argtypes = [C.c_void_p, C.c_uint, C.c_size_t]
+    L.kh_tones_execute.argtypes = [C.c_void_p, C.c_uint]
+    L.kh_tones_sync.argtypes = [C.c_void_p]
+    L.kh_tones_read_pl.argtypes = [C.c_void_p, C.c_uint, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]
+    L.kh_tones_read_dtmf.argtypes = [C.c_void_p, C.c_uint, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]
     _lib = L
     return L
 
@@ -485,4 +497,50 @@ class Afsk:
     def close(self):
         if self.h:
             self.lib.kh_afsk_destroy(self.h)
+            self.h = None
+
+
+class Tones:
+    """pl.c's CTCSS and DTMF decoders for `sessions` PCM streams (kh_tones_*)."""
+    WINDOW = 2400
+    PL = np.dtype([("tone", "<f4"), ("snr", "<f4"), ("e0", "<f4"), ("e1", "<f4"), ("index", "<i4")])
+    DTMF = np.dtype([("digit", "<i4"), ("low_index", "<i4"), ("high_index", "<i4"), ("low_snr", "<f4"), ("high_snr", "<f4")])
+
+    def __init__(self, sessions, max_windows):
+        self.lib = lib()
+        self.S, self.W = sessions, max_windows
+        self.h = self.lib.kh_tones_create(sessions, max_windows)
+        if not self.h:
+            raise RuntimeError("kh_tones_create: " + last_error())
+
+    def write_pcm(self, session, pcm_be):
+        pcm_be = np.ascontiguousarray(pcm_be, np.int16)
+        _check(self.lib.kh_tones_write_pcm(self.h, session, pcm_be.ctypes.data, pcm_be.size), "kh_tones_write_pcm")
+
+    def commit_pcm(self, session, nwords):
+        _check(self.lib.kh_tones_commit_pcm(self.h, session, nwords), "kh_tones_commit_pcm")
+
+    def execute(self, nwindows, sync=True):
+        _check(self.lib.kh_tones_execute(self.h, nwindows), "kh_tones_execute")
+        if sync:
+            _check(self.lib.kh_tones_sync(self.h), "kh_tones_sync")
+
+    def sync(self):
+        _check(self.lib.kh_tones_sync(self.h), "kh_tones_sync")
+
+    def pl(self, session):
+        out = np.zeros(self.W // 5 + 1, self.PL)
+        n = C.c_size_t()
+        _check(self.lib.kh_tones_read_pl(self.h, session, out.ctypes.data, out.size, C.byref(n)), "kh_tones_read_pl")
+        return out[:n.value]
+
+    def dtmf(self, session):
+        out = np.zeros(self.W, self.DTMF)
+        n = C.c_size_t()
+        _check(self.lib.kh_tones_read_dtmf(self.h, session, out.ctypes.data, out.size, C.byref(n)), "kh_tones_read_dtmf")
+        return out[:n.value]
+
+    def close(self):
+        if self.h:
+            self.lib.kh_tones_destroy(self.h)
             self.h = None

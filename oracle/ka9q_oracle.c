@@ -1072,6 +1072,101 @@ int orc_afsk_block(struct orc_afsk_state *st, const float complex *y, int n_in, 
   return nframes;
 }
 
+/* =========================================================== pl.c */
+const float orc_pl_tones[ORC_PL_NTONES] = { /* pl.c:36-44 */
+    67.0,  69.3,  71.9,  74.4,  77.0,  79.7,  82.5,  85.4,  88.5,  91.5,  94.8,  97.4,
+    100.0, 103.5, 107.2, 110.9, 114.8, 118.8, 123.0, 127.3, 131.8, 136.5, 141.3, 146.2,
+    150.0, 151.4, 156.7, 162.2, 167.9, 173.8, 179.9, 186.2, 192.8, 199.5, 206.5, 213.8,
+    221.3, 229.1, 237.1, 245.5, 254.1, 159.8, 165.5, 171.3, 177.3, 183.5, 189.9, 196.6,
+    203.5, 210.7, 218.1, 225.7, 233.6, 241.8, 250.3,
+};
+static const float dtmf_low_tones[4] = {697, 770, 852, 941};      /* pl.c:48 */
+static const float dtmf_high_tones[4] = {1209, 1336, 1477, 1633}; /* pl.c:49 */
+static const char dtmf_matrix[4][4] = {{'1', '2', '3', 'A'}, {'4', '5', '6', 'B'}, {'7', '8', '9', 'C'}, {'*', '0', '#', 'D'}};
+#define PL_SAMPRATE 48000 /* pl.c:25 */
+
+void orc_pl_init(struct orc_pl_session *sp) { /* make_session, pl.c:305,317-329 */
+  memset(sp, 0, sizeof *sp);
+  for (int n = 0; n < ORC_PL_NTONES; n++)
+    orc_set_osc(&sp->pl_osc[n], orc_pl_tones[n] / PL_SAMPRATE, 9); /* rate 9 cycles/sample^2: cispi(18) is 1 - 2.2e-15 i */
+  for (int n = 0; n < 4; n++) {
+    orc_set_osc(&sp->dtmf_low_osc[n], dtmf_low_tones[n] / PL_SAMPRATE, 0);
+    orc_set_osc(&sp->dtmf_high_osc[n], dtmf_high_tones[n] / PL_SAMPRATE, 0);
+  }
+}
+static void process_pl(struct orc_pl_session *sp, struct orc_pl_result *r) { /* pl.c:360-387 */
+  sp->pl_audio_count = 0;
+  /* qsort in descending energy (pl.c:369): only the two largest are used */
+  float e0 = -1, e1 = -1;
+  int i0 = 0;
+  for (int n = 0; n < ORC_PL_NTONES; n++) {
+    float const e = cnrmf_(sp->pl_integrators[n]);
+    sp->pl_integrators[n] = 0;
+    if (e > e0) {
+      e1 = e0;
+      e0 = e;
+      i0 = n;
+    } else if (e > e1)
+      e1 = e;
+  }
+  float const pl_snr = 10 * log10f(e0) - 10 * log10f(e1); /* power2dB, dsp.h:74 */
+  r->tone = pl_snr >= 6 ? orc_pl_tones[i0] : 0;
+  r->snr = pl_snr;
+  r->e0 = e0;
+  r->e1 = e1;
+  r->index = i0;
+}
+static int dtmf_group(float complex *integ, float *snr_out) { /* pl.c:395-410 */
+  int index = -1;
+  float max_energy = 0, total_energy = 0;
+  for (int n = 0; n < 4; n++) {
+    float energy = cnrmf_(integ[n]);
+    integ[n] = 0;
+    total_energy += energy;
+    if (energy >= max_energy) {
+      max_energy = energy;
+      index = n;
+    }
+  }
+  float const snr = max_energy / (total_energy - max_energy);
+  if (snr < 10) index = -1; /* (a NaN from digital silence does not take this branch) */
+  *snr_out = snr;
+  return index;
+}
+static void process_dtmf(struct orc_pl_session *sp, struct orc_dtmf_result *r) { /* pl.c:390-439 */
+  sp->dtmf_audio_count = 0;
+  r->low_index = dtmf_group(sp->dtmf_low_integrators, &r->low_snr);
+  r->high_index = dtmf_group(sp->dtmf_high_integrators, &r->high_snr);
+  r->digit = (r->low_index != -1 && r->high_index != -1) ? dtmf_matrix[r->low_index][r->high_index] : 0;
+}
+void orc_pl_samples(struct orc_pl_session *sp, const int16_t *pcm_be, int count, struct orc_pl_result *pl, int maxpl,
+                    int *npl, struct orc_dtmf_result *dt, int maxdt, int *ndt) {
+  float const SCALE16 = 1. / SHRT_MAX; /* pl.c:29 */
+  int np = 0, nd = 0;
+  for (int k = 0; k < count; k++) { /* pl.c:249-276 */
+    float samp = SCALE16 * (short)swap16((uint16_t)pcm_be[k]);
+    for (int n = 0; n < ORC_PL_NTONES; n++) sp->pl_integrators[n] += samp * orc_step_osc(&sp->pl_osc[n]);
+    if (++sp->pl_audio_count >= ORC_PL_BLOCKSIZE) {
+      struct orc_pl_result r;
+      process_pl(sp, &r);
+      if (np < maxpl) pl[np] = r;
+      np++;
+    }
+    for (int n = 0; n < 4; n++) {
+      sp->dtmf_low_integrators[n] += samp * orc_step_osc(&sp->dtmf_low_osc[n]);
+      sp->dtmf_high_integrators[n] += samp * orc_step_osc(&sp->dtmf_high_osc[n]);
+    }
+    if (++sp->dtmf_audio_count >= ORC_DTMF_BLOCKSIZE) {
+      struct orc_dtmf_result r;
+      process_dtmf(sp, &r);
+      if (nd < maxdt) dt[nd] = r;
+      nd++;
+    }
+  }
+  if (npl) *npl = np;
+  if (ndt) *ndt = nd;
+}
+
 /* =========================================================== misc.c */
 uint32_t orc_nextfastfft(uint32_t n) { /* misc.c:129-148 */
   uint64_t result = 4288306050ULL;

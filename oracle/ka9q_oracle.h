@@ -265,6 +265,34 @@ void orc_afsk_init(struct orc_afsk_state *st);                                  
 int orc_afsk_block(struct orc_afsk_state *st, const float complex *y, int n, int sample_base,
                    struct orc_ax25_frame *out, int maxframes, struct orc_afsk_bit *bits, int maxbits, int *nbits);
 
+/* ---------------------------------------------------------------- pl.c (CTCSS "PL" tone and DTMF correlator banks) */
+#define ORC_PL_NTONES 55          /* pl.c:36-44 */
+#define ORC_PL_BLOCKSIZE 12000    /* pl.c:26: 250 ms at 48 kS/s */
+#define ORC_DTMF_BLOCKSIZE 2400   /* pl.c:27: 50 ms */
+extern const float orc_pl_tones[ORC_PL_NTONES];
+struct orc_pl_session {           /* the DSP members of pl.c's struct session, 62-83 */
+  float complex pl_integrators[ORC_PL_NTONES];
+  struct orc_osc pl_osc[ORC_PL_NTONES];
+  float complex dtmf_low_integrators[4], dtmf_high_integrators[4];
+  struct orc_osc dtmf_low_osc[4], dtmf_high_osc[4];
+  int pl_audio_count, dtmf_audio_count;
+};
+struct orc_pl_result {            /* process_pl, pl.c:360-387 */
+  float tone;                     /* Hz, 0 = none */
+  float snr;                      /* dB between the two strongest correlators */
+  float e0, e1;                   /* their energies */
+  int index;                      /* of the strongest */
+};
+struct orc_dtmf_result {          /* process_dtmf, pl.c:390-439 */
+  int digit;                      /* character, 0 = none */
+  int low_index, high_index;
+  float low_snr, high_snr;
+};
+void orc_pl_init(struct orc_pl_session *sp);                                                   /* pl.c:317-329 */
+/* pl.c:248-276 over n network-order samples; results of every integration interval that ends inside */
+void orc_pl_samples(struct orc_pl_session *sp, const int16_t *pcm_be, int n, struct orc_pl_result *pl, int maxpl,
+                    int *npl, struct orc_dtmf_result *dt, int maxdt, int *ndt);
+
 /* ---------------------------------------------------------------- misc.c */
 uint32_t orc_nextfastfft(uint32_t n);                                                          /* misc.c:129 */
 

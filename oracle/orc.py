@@ -109,6 +109,21 @@ class AfskBit(C.Structure):  # struct orc_afsk_bit
     _fields_ = [("sample", C.c_int), ("cur_val", C.c_float)]
 
 
+class PlSession(C.Structure):  # struct orc_pl_session
+    _fields_ = [("pl_integrators", Cf * 55), ("pl_osc", Osc * 55), ("dtmf_low_integrators", Cf * 4),
+                ("dtmf_high_integrators", Cf * 4), ("dtmf_low_osc", Osc * 4), ("dtmf_high_osc", Osc * 4),
+                ("pl_audio_count", C.c_int), ("dtmf_audio_count", C.c_int)]
+
+
+class PlResult(C.Structure):
+    _fields_ = [("tone", C.c_float), ("snr", C.c_float), ("e0", C.c_float), ("e1", C.c_float), ("index", C.c_int)]
+
+
+class DtmfResult(C.Structure):
+    _fields_ = [("digit", C.c_int), ("low_index", C.c_int), ("high_index", C.c_int), ("low_snr", C.c_float),
+                ("high_snr", C.c_float)]
+
+
 class Notch(C.Structure):
     _fields_ = [("osc_phase", Cd), ("osc_step", Cd), ("dcstate", Cf), ("bw", C.c_float)]
 
@@ -209,6 +224,10 @@ def lib(fast=False):
     L.orc_afsk_init.argtypes = [vp]
     L.orc_afsk_init.restype = None
     L.orc_afsk_block.argtypes = [vp, vp, i, i, vp, i, vp, i, vp]
+    L.orc_pl_init.argtypes = [vp]
+    L.orc_pl_init.restype = None
+    L.orc_pl_samples.argtypes = [vp, vp, i, vp, i, vp, vp, i, vp]
+    L.orc_pl_samples.restype = None
     _libs[path] = L
     return L
 
@@ -486,3 +505,29 @@ class AfskSession:
     def close(self):
         self.L.orc_delete_filter_output(self.fout)
         self.L.orc_delete_filter_input(self.fin)
+
+
+# ---------------------------------------------------------------- pl.c: CTCSS and DTMF correlator banks per PCM session
+PL_BLOCK, DTMF_BLOCK = 12000, 2400  # pl.c:26-27
+
+
+def pl_tones(fast=False):
+    return np.array(list((C.c_float * 55).in_dll(lib(fast), "orc_pl_tones")), np.float32)
+
+
+class PlSessionRunner:
+    def __init__(self, fast=False):
+        self.L = lib(fast)
+        self.sp = PlSession()
+        self.L.orc_pl_init(C.addressof(self.sp))
+
+    def samples(self, pcm_be):
+        """Returns (pl results, dtmf results) of the integration intervals that end inside these samples."""
+        pcm_be = np.ascontiguousarray(pcm_be, np.int16)
+        maxpl, maxdt = pcm_be.size // PL_BLOCK + 2, pcm_be.size // DTMF_BLOCK + 2
+        pl, dt = (PlResult * maxpl)(), (DtmfResult * maxdt)()
+        npl, ndt = C.c_int(0), C.c_int(0)
+        self.L.orc_pl_samples(C.addressof(self.sp), _vp(pcm_be), pcm_be.size, pl, maxpl, C.byref(npl), dt, maxdt, C.byref(ndt))
+        return ([dict(tone=r.tone, snr=r.snr, e0=r.e0, e1=r.e1, index=r.index) for r in pl[:npl.value]],
+                [dict(digit=chr(r.digit) if r.digit else "", low_index=r.low_index, high_index=r.high_index,
+                      low_snr=r.low_snr, high_snr=r.high_snr) for r in dt[:ndt.value]])
