@@ -218,11 +218,19 @@ def main():
                     and os.environ.get("KA9Q_HIP_CHAN_WAVE", "1") != "0")
         sb = stage_bytes(bincount, n0_rides)
         stages = {}
+        # stages whose work rides in another kernel still record an (empty) event pair of ~5 us: no rate for those
+        fused_ingest = N > 8192 and os.environ.get("KA9Q_HIP_FUSED_INGEST", "1") != "0"
+        empty = {"ingest": "in fft1 (kh_fft_cols reads the raw ring)"} if fused_ingest else {}
+        if n0_rides:
+            empty["n0"] = "iteration 1 in chan (kh_back_a), final sums in demod (kh_fm_finish_w)"
         for name, (ms, n) in st.items():
             if n:
                 avg = ms / n
-                stages[name] = {"ms": round(avg, 5), "GBps": round(sb[name] / (avg * 1e-3) / 1e9, 1) if avg > 0 else None}
-        dom = max((k for k in stages if k != "carry"), key=lambda k: stages[k]["ms"])
+                if name in empty:
+                    stages[name] = {"ms": round(avg, 5), "GBps": None, "empty": empty[name]}
+                else:
+                    stages[name] = {"ms": round(avg, 5), "GBps": round(sb[name] / (avg * 1e-3) / 1e9, 1) if avg > 0 else None}
+        dom = max((k for k in stages if k != "carry" and k not in empty), key=lambda k: stages[k]["ms"])
         traffic = None  # HBM bytes per launch of that kernel from the committed PMC passes (profiles/, tools/summarize_prof.py)
         try:
             prof = json.load(open(os.path.join(ROOT, "profiles", "r01_step4_hbm_traffic.json")))["kernels"]

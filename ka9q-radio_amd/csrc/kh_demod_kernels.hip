@@ -715,6 +715,38 @@ __device__ __forceinline__ void dosc_step(DOsc &o) { // step_osc with rate == 0
   }
 }
 
+// cispi(x) for |x| <= 1 (osc.c:30 with the PLL's clamp |f| <= 0.49, osc.c:96): quadrant by rounding 2x, Taylor
+// series of sin(pi r), cos(pi r) in r^2 on |r| <= 1/4 (nine terms each: 1.1e-16 of the exact values on a 20001-point
+// grid).  About 25 fp64 operations; the library's sincospi is several times that, and this sits in the per-sample
+// recurrence of every PLL channel.
+__device__ __forceinline__ void cispi_small(double x, double *sn, double *cs) {
+  double const k = rint(2.0 * x);
+  double const r = fma(k, -0.5, x);
+  double const t = r * r;
+  double ps = 7.952054001475513e-07, pc = 4.303069587032947e-06;
+  ps = fma(ps, t, -2.1915353447830217e-05);
+  pc = fma(pc, t, -0.0001046381049248457);
+  ps = fma(ps, t, 0.00046630280576761255);
+  pc = fma(pc, t, 0.0019295743094039231);
+  ps = fma(ps, t, -0.0073704309457143504);
+  pc = fma(pc, t, -0.02580689139001406);
+  ps = fma(ps, t, 0.08214588661112823);
+  pc = fma(pc, t, 0.2353306303588932);
+  ps = fma(ps, t, -0.5992645293207921);
+  pc = fma(pc, t, -1.3352627688545895);
+  ps = fma(ps, t, 2.5501640398773455);
+  pc = fma(pc, t, 4.0587121264167685);
+  ps = fma(ps, t, -5.16771278004997);
+  pc = fma(pc, t, -4.934802200544679);
+  ps = fma(ps, t, 3.141592653589793);
+  pc = fma(pc, t, 1.0);
+  ps *= r;
+  int const q = (int)k & 3; // x = k/2 + r: rotate (cos, sin) of pi r by q quarter turns
+  double const s0 = (q & 1) ? pc : ps, c0 = (q & 1) ? ps : pc;
+  *sn = (q == 2 || q == 3) ? -s0 : s0;
+  *cs = (q == 1 || q == 2) ? -c0 : c0;
+}
+
 // ================================================================ linear: linear.c:57-156, one lane per channel
 __global__ __launch_bounds__(64) void kh_demod_linear(float2 *__restrict__ baseband, size_t bb_stride, int olen,
                                                       int nblocks, const DemodDesc *__restrict__ descs,
@@ -743,7 +775,17 @@ __global__ __launch_bounds__(64) void kh_demod_linear(float2 *__restrict__ baseb
   vco.sre = 1;
   vco.sim = 0;
   float const snrthresh = 2; // linear.c:32
+  // shift frequency 0 with the phasor at exactly 1 (the usual case, radio.c:359 with no shift): every product is
+  // exact and the phasor never moves, so the multiply and the step are skipped; only the renormalisation count runs on
+  bool const shift_active = !(shift.sre == 1.0 && shift.sim == 0.0 && shift.re == 1.0 && shift.im == 0.0);
+  int shift_skipped = 0;
 
+  // The PLL pass (linear.c:81-97) and the output pass (linear.c:114-148) of a block are run sample by sample in one
+  // loop: the output pass reads only what the PLL pass has just written back (linear.c:91), and nothing the PLL pass
+  // uses changes in the output pass, so the order of every operation on every variable is the reference's.  Samples
+  // come in groups of G, the next group already in flight while this one is worked on: each lane walks its own row,
+  // and a load per sample would put a memory round trip into every step of the recurrence.
+  constexpr int G = 8;
   for (int b = 0; b < nblocks; b++) {
     float2 *yb = y + (size_t)b * olen;
     kh_status r;
@@ -767,33 +809,96 @@ __global__ __launch_bounds__(64) void kh_demod_linear(float2 *__restrict__ baseb
         s.pll_lock = 0;
       }
       r.lock_timer = (float)s.lock_count;
-      float signal = 0, noise = 0;
-      for (int n = 0; n < olen; n++) { // linear.c:81-97
-        float2 v = yb[n];
-        float2 const ph = make_float2((float)vco.re, (float)vco.im);
-        v = cmulc(v, ph); // s *= conjf(pll.vco.phasor)
-        float phase;
-        if (d.square)
-          phase = atan2f(2 * v.x * v.y, v.x * v.x - v.y * v.y); // cargf(s*s)
-        else
-          phase = atan2f(v.y, v.x);
-        // run_pll, osc.c:91-107
-        float feedback = d.pll_integrator_gain * s.pll_integrator + d.pll_prop_gain * phase;
-        s.pll_integrator += phase;
-        feedback = (double)feedback > 0.49 ? (float)0.49 : (double)feedback < -0.49 ? (float)-0.49 : feedback;
-        // set_osc(&pll->vco, feedback, 0), osc.c:22-36
-        if (isnan(vco.re) || isnan(vco.im) || vco.re * vco.re + vco.im * vco.im < 0.9) {
-          vco.re = 1;
-          vco.im = 0;
-          vco.steps = 0;
+    }
+    float signal = 0, noise = 0, energy = 0, output_level = 0;
+    float2 nxt[G];
+#pragma unroll
+    for (int u = 0; u < G; u++) nxt[u] = u < olen ? yb[u] : make_float2(0.f, 0.f);
+    for (int n0 = 0; n0 < olen; n0 += G) {
+      float2 cur[G];
+#pragma unroll
+      for (int u = 0; u < G; u++) cur[u] = nxt[u];
+#pragma unroll
+      for (int u = 0; u < G; u++) nxt[u] = n0 + G + u < olen ? yb[n0 + G + u] : make_float2(0.f, 0.f);
+#pragma unroll
+      for (int u = 0; u < G; u++) {
+        int const n = n0 + u;
+        if (n >= olen) break;
+        float2 v = cur[u];
+        if (d.pll) { // linear.c:81-97
+          float2 const ph = make_float2((float)vco.re, (float)vco.im);
+          v = cmulc(v, ph); // s *= conjf(pll.vco.phasor)
+          float phase;
+          if (d.square)
+            phase = atan2f(2 * v.x * v.y, v.x * v.x - v.y * v.y); // cargf(s*s)
+          else
+            phase = atan2f(v.y, v.x);
+          // run_pll, osc.c:91-107
+          float feedback = d.pll_integrator_gain * s.pll_integrator + d.pll_prop_gain * phase;
+          s.pll_integrator += phase;
+          feedback = (double)feedback > 0.49 ? (float)0.49 : (double)feedback < -0.49 ? (float)-0.49 : feedback;
+          // set_osc(&pll->vco, feedback, 0), osc.c:22-36
+          if (isnan(vco.re) || isnan(vco.im) || vco.re * vco.re + vco.im * vco.im < 0.9) {
+            vco.re = 1;
+            vco.im = 0;
+            vco.steps = 0;
+          }
+          s.vco_freq = (double)feedback;
+          cispi_small(2 * s.vco_freq, &vco.sim, &vco.sre); // cispi(2 f), osc.c:30
+          dosc_step(vco);
+          signal += v.x * v.x;
+          noise += v.y * v.y;
         }
-        s.vco_freq = (double)feedback;
-        sincos(2 * s.vco_freq * M_PI, &vco.sim, &vco.sre);
-        dosc_step(vco);
-        yb[n] = v; // linear.c:91
-        signal += v.x * v.x;
-        noise += v.y * v.y;
+        // linear.c:114-148
+        // complex float * complex double -> double product, rounded to float
+        float2 sm = v;
+        if (shift_active) {
+          sm = make_float2((float)((double)v.x * shift.re - (double)v.y * shift.im),
+                           (float)((double)v.x * shift.im + (double)v.y * shift.re));
+          dosc_step(shift);
+        } else {
+          shift_skipped++;
+        }
+        float const norm = sm.x * sm.x + sm.y * sm.y;
+        energy += norm;
+        float const amplitude = sqrtf(norm);
+        if (d.agc) { // linear.c:127-136
+          if (isnan(s.agc_gain) || amplitude * s.agc_gain > d.headroom) {
+            s.agc_gain = d.headroom / amplitude;
+            s.hangcount = (int)d.hangtime;
+          } else if (s.hangcount > 0) {
+            s.hangcount--;
+          } else {
+            s.agc_gain *= d.recovery_rate;
+          }
+        }
+        size_t const o = (size_t)b * olen + n;
+        if (d.env) {
+          float const smp = amplitude * s.agc_gain;
+          output_level += smp * smp;
+          if (ao) ao[o] = smp;
+          po[o] = pcm_word(smp, big_endian);
+          if (d.pll) yb[n] = v; // linear.c:91
+        } else if (d.channels == 1) {
+          float const smp = sm.x * s.agc_gain;
+          output_level += smp * smp;
+          if (ao) ao[o] = smp;
+          po[o] = pcm_word(smp, big_endian);
+          if (d.pll) yb[n] = v; // linear.c:91
+        } else {
+          float2 const w = make_float2(sm.x * s.agc_gain, sm.y * s.agc_gain);
+          yb[n] = w; // linear.c:145
+          output_level += w.x * w.x + w.y * w.y;
+          if (ao) {
+            ao[2 * o] = w.x;
+            ao[2 * o + 1] = w.y;
+          }
+          po[2 * o] = pcm_word(w.x, big_endian);
+          po[2 * o + 1] = pcm_word(w.y, big_endian);
+        }
       }
+    }
+    if (d.pll) {
       float cphase = (float)atan2(vco.im, vco.re); // linear.c:98
       if (d.square) cphase /= 2;
       r.cphase = cphase;
@@ -804,49 +909,6 @@ __global__ __launch_bounds__(64) void kh_demod_linear(float2 *__restrict__ baseb
       } else
         s.snr = NAN;
     }
-    float energy = 0, output_level = 0;
-    for (int n = 0; n < olen; n++) { // linear.c:114-148
-      float2 const v = yb[n];
-      // complex float * complex double -> double product, rounded to float
-      float2 const sm = make_float2((float)((double)v.x * shift.re - (double)v.y * shift.im),
-                                    (float)((double)v.x * shift.im + (double)v.y * shift.re));
-      dosc_step(shift);
-      float const norm = sm.x * sm.x + sm.y * sm.y;
-      energy += norm;
-      float const amplitude = sqrtf(norm);
-      if (d.agc) { // linear.c:127-136
-        if (isnan(s.agc_gain) || amplitude * s.agc_gain > d.headroom) {
-          s.agc_gain = d.headroom / amplitude;
-          s.hangcount = (int)d.hangtime;
-        } else if (s.hangcount > 0) {
-          s.hangcount--;
-        } else {
-          s.agc_gain *= d.recovery_rate;
-        }
-      }
-      size_t const o = (size_t)b * olen + n;
-      if (d.env) {
-        float const smp = amplitude * s.agc_gain;
-        output_level += smp * smp;
-        if (ao) ao[o] = smp;
-        po[o] = pcm_word(smp, big_endian);
-      } else if (d.channels == 1) {
-        float const smp = sm.x * s.agc_gain;
-        output_level += smp * smp;
-        if (ao) ao[o] = smp;
-        po[o] = pcm_word(smp, big_endian);
-      } else {
-        float2 const w = make_float2(sm.x * s.agc_gain, sm.y * s.agc_gain);
-        yb[n] = w; // linear.c:145
-        output_level += w.x * w.x + w.y * w.y;
-        if (ao) {
-          ao[2 * o] = w.x;
-          ao[2 * o + 1] = w.y;
-        }
-        po[2 * o] = pcm_word(w.x, big_endian);
-        po[2 * o + 1] = pcm_word(w.y, big_endian);
-      }
-    }
     r.output_level = output_level / (olen * d.channels);
     r.bb_power = energy / olen;
     r.snr = s.snr;
@@ -856,7 +918,7 @@ __global__ __launch_bounds__(64) void kh_demod_linear(float2 *__restrict__ baseb
   }
   s.shift_re = shift.re;
   s.shift_im = shift.im;
-  s.shift_steps = shift.steps;
+  s.shift_steps = (shift.steps + shift_skipped) % 16384; // Renorm_rate, osc.c:11
   s.vco_re = vco.re;
   s.vco_im = vco.im;
   s.vco_steps = vco.steps;
