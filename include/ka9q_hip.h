@@ -323,6 +323,32 @@ int kh_tones_sync(kh_tones *);
 int kh_tones_read_pl(kh_tones *, unsigned int session, struct kh_pl_result *out, size_t max, size_t *n);
 int kh_tones_read_dtmf(kh_tones *, unsigned int session, struct kh_dtmf_result *out, size_t max, size_t *n);
 
+/* ---- SDR front-end corrections in front of decimate.c.  Pointers may be host or device memory
+ * (device pointers skip the copies, so correct -> kh_decimate_rails -> pack can stay on the GPU). */
+struct kh_fe_state {   /* sdr->DC, sinphi, imbalance, clips, in_power and the gains of hackrf.c:136-139,815 / funcube.c:331-334 */
+  float dc_re, dc_im;
+  float sinphi, imbalance;  /* hackrf.c leaves imbalance at 0 on start (zeroed global); funcube.c likewise */
+  float gain_i, gain_q, secphi, tanphi; /* start at 1, 1, 1, 0 */
+  int32_t rotate_phase;
+  int32_t clips;
+  float in_power;
+};
+/* rx_callback, hackrf.c:822-919, for nblocks consecutive transfers of `samples` int8 I/Q pairs: clip at -1, DC removal,
+ * gain balance, phase correction, Fs/4 rotation (offset = Offset, hackrf.c:77) into the two float rails
+ * (Sampbuffer_i/q); the estimates are updated after every transfer as the reference does (906-917).
+ * rate_factor = 1/(ADC_samprate*Power_alpha), hackrf.c:277. */
+int kh_hackrf_correct(struct kh_fe_state *state, const int8_t *iq, unsigned int samples, unsigned int nblocks, int offset,
+                      float rate_factor, float *out_i, float *out_q);
+/* funcube.c:364-428 for nblocks blocks of `blocksize` int16 pairs (host order in, network order out, in place).
+ * rate_factor = Blocksize/(ADC_samprate*Power_alpha), funcube.c:340. */
+int kh_funcube_correct(struct kh_fe_state *state, int16_t *sampbuf, unsigned int blocksize, unsigned int nblocks,
+                       float rate_factor);
+/* hackrf.c:511-573: chunk decimated samples x filter_atten -> payload bytes (KH_PT_IQ16LE: 4/sample, KH_PT_IQ12: 3,
+ * KH_PT_IQ8: 2); *output_energy receives the sum the reference divides into sdr->out_power (566-573).
+ * Out-of-range values saturate (the reference's float -> short conversion is undefined there: "Clip?"). */
+int kh_hackrf_pack(int payload, const float *ip, const float *qp, unsigned int chunk, float filter_atten, void *out,
+                   float *output_energy);
+
 void *kh_bank_stream(kh_bank *); /* hipStream_t */
 /* per-kernel timing with HIP events on the bank's stream.  Stages: */
 enum kh_stage { KH_STAGE_INGEST = 0, KH_STAGE_FFT1, KH_STAGE_FFT2, KH_STAGE_N0, KH_STAGE_CHAN, KH_STAGE_DEMOD,

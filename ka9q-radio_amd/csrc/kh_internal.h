@@ -240,4 +240,19 @@ int launch_tones(hipStream_t st, const void *pcm_be, size_t pcm_stride, const To
                  int nwindows, int nsess, TonesState *states, void *pl, int max_pl, int *npl, void *dt,
                  unsigned long long base);
 
+// front-end corrections (kh_frontend_kernels.hip, kh_frontend.cpp)
+struct FeParams { // what one block is corrected with (the state before that block's update)
+  float dc_re, dc_im, gain_i, gain_q, secphi, tanphi;
+  int rotate_phase, pad;
+};
+} // namespace kh
+struct kh_fe_state;
+namespace kh {
+int fe_chunks(int samples);
+int fe_pack_groups(int chunk);
+int launch_frontend(hipStream_t st, int funcube, const void *raw, int samples, int nblocks, int offset, float rate_factor,
+                    kh_fe_state *state, long long *part, FeParams *params, float *out_i, float *out_q, void *out_be);
+int launch_fe_pack(hipStream_t st, int pt, const float *ip, const float *qp, int chunk, float atten, void *out,
+                   float *energy_part);
+
 } // namespace kh

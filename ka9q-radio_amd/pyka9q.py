@@ -34,6 +34,7 @@ EXPORTS = [
     "kh_afsk_read_baseband",
     "kh_tones_create", "kh_tones_destroy", "kh_tones_write_pcm", "kh_tones_pcm_device_ptr", "kh_tones_commit_pcm",
     "kh_tones_execute", "kh_tones_sync", "kh_tones_read_pl", "kh_tones_read_dtmf",
+    "kh_hackrf_correct", "kh_funcube_correct", "kh_hackrf_pack",
 ]
 
 
@@ -183,6 +184,9 @@ def lib():
     L.kh_tones_sync.argtypes = [C.c_void_p]
     L.kh_tones_read_pl.argtypes = [C.c_void_p, C.c_uint, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]
     L.kh_tones_read_dtmf.argtypes = [C.c_void_p, C.c_uint, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]
+    L.kh_hackrf_correct.argtypes = [C.c_void_p, C.c_void_p, C.c_uint, C.c_uint, C.c_int, C.c_float, C.c_void_p, C.c_void_p]
+    L.kh_funcube_correct.argtypes = [C.c_void_p, C.c_void_p, C.c_uint, C.c_uint, C.c_float]
+    L.kh_hackrf_pack.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_uint, C.c_float, C.c_void_p, C.POINTER(C.c_float)]
     _lib = L
     return L
 
@@ -544,3 +548,39 @@ class Tones:
         if self.h:
             self.lib.kh_tones_destroy(self.h)
             self.h = None
+
+
+FE_STATE = np.dtype([("dc_re", "<f4"), ("dc_im", "<f4"), ("sinphi", "<f4"), ("imbalance", "<f4"), ("gain_i", "<f4"),
+                     ("gain_q", "<f4"), ("secphi", "<f4"), ("tanphi", "<f4"), ("rotate_phase", "<i4"), ("clips", "<i4"),
+                     ("in_power", "<f4")])
+
+
+def fe_state(imbalance=0.0):
+    s = np.zeros(1, FE_STATE)
+    s["imbalance"] = imbalance
+    s["gain_i"] = s["gain_q"] = s["secphi"] = 1.0
+    return s
+
+
+def hackrf_correct(state, iq, samples, nblocks, offset, rate_factor):
+    iq = np.ascontiguousarray(iq, np.int8)
+    assert iq.size == 2 * samples * nblocks
+    oi, oq = np.empty(samples * nblocks, np.float32), np.empty(samples * nblocks, np.float32)
+    _check(lib().kh_hackrf_correct(state.ctypes.data, iq.ctypes.data, samples, nblocks, offset, rate_factor, oi.ctypes.data,
+                                   oq.ctypes.data), "kh_hackrf_correct")
+    return oi, oq
+
+
+def funcube_correct(state, sampbuf, blocksize, nblocks, rate_factor):
+    buf = np.ascontiguousarray(sampbuf, np.int16).copy()
+    assert buf.size == 2 * blocksize * nblocks
+    _check(lib().kh_funcube_correct(state.ctypes.data, buf.ctypes.data, blocksize, nblocks, rate_factor), "kh_funcube_correct")
+    return buf
+
+
+def hackrf_pack(payload, ip, qp, atten):
+    ip, qp = np.ascontiguousarray(ip, np.float32), np.ascontiguousarray(qp, np.float32)
+    out = np.zeros(ip.size * {KH_PT_IQ16LE: 4, KH_PT_IQ12: 3, KH_PT_IQ8: 2}[payload], np.uint8)
+    e = C.c_float()
+    _check(lib().kh_hackrf_pack(payload, ip.ctypes.data, qp.ctypes.data, ip.size, atten, out.ctypes.data, C.byref(e)), "kh_hackrf_pack")
+    return out, e.value

@@ -1167,6 +1167,130 @@ void orc_pl_samples(struct orc_pl_session *sp, const int16_t *pcm_be, int count,
   if (ndt) *ndt = nd;
 }
 
+/* =========================================================== front-end corrections: hackrf.c, funcube.c */
+void orc_fe_init(struct orc_fe_state *st, float imbalance0) {
+  memset(st, 0, sizeof *st);
+  st->imbalance = imbalance0;
+  st->gain_i = st->gain_q = st->secphi = 1; /* hackrf.c:136-139, funcube.c:331-334 */
+  st->tanphi = 0;
+}
+static void fe_update_gains(struct orc_fe_state *st) { /* hackrf.c:913-916, funcube.c:424-427 */
+  st->gain_q = sqrtf(0.5 * (1 + st->imbalance));
+  st->gain_i = sqrtf(0.5 * (1 + 1. / st->imbalance));
+  st->secphi = 1 / sqrtf(1 - st->sinphi * st->sinphi);
+  st->tanphi = st->sinphi * st->secphi;
+}
+void orc_hackrf_rx_block(struct orc_fe_state *st, const int8_t *dp, int samples, int offset, float Rate_factor,
+                         float *out_i, float *out_q) { /* hackrf.c:822-919 */
+  float const SCALE8 = 1. / INT8_MAX; /* hackrf.c:64 */
+  float const DC_alpha = .001;        /* hackrf.c:66 */
+  float complex samp_sum = 0;
+  float i_energy = 0, q_energy = 0, dotprod = 0;
+  for (int n = 0; n < samples; n++) {
+    float re = SCALE8 * (float)*dp++;
+    float im = SCALE8 * (float)*dp++;
+    if (im < -1) {
+      st->clips++;
+      im = -1;
+    }
+    if (re < -1) {
+      st->clips++;
+      re = -1;
+    }
+    float complex samp = CMPLXF(re, im);
+    samp_sum += samp;
+    samp -= st->DC;
+    re = crealf(samp);
+    im = cimagf(samp);
+    i_energy += re * re;
+    q_energy += im * im;
+    re *= st->gain_i;
+    im *= st->gain_q;
+    dotprod += re * im;
+    im = st->secphi * im - st->tanphi * re;
+    switch (st->rotate_phase) { /* hackrf.c:878-896 */
+    default:
+    case 0: out_i[n] = re; out_q[n] = im; break;
+    case 1: out_i[n] = -im; out_q[n] = re; break;
+    case 2: out_i[n] = -re; out_q[n] = -im; break;
+    case 3: out_i[n] = im; out_q[n] = -re; break;
+    }
+    st->rotate_phase += offset;
+    st->rotate_phase &= 3;
+  }
+  st->DC += DC_alpha * (samp_sum / samples - st->DC); /* hackrf.c:906 */
+  float block_energy = i_energy + q_energy;
+  if (block_energy > 0) {
+    st->in_power = block_energy / samples;
+    st->imbalance += Rate_factor * samples * ((i_energy / q_energy) - st->imbalance);
+    float dpn = 2 * dotprod / block_energy;
+    st->sinphi += Rate_factor * samples * (dpn - st->sinphi);
+    fe_update_gains(st);
+  }
+}
+void orc_funcube_block(struct orc_fe_state *st, int16_t *sampbuf, int Blocksize, float rate_factor) { /* funcube.c:364-428 */
+  float const SCALE16 = 1. / SHRT_MAX; /* funcube.c:64 */
+  float const DC_alpha = 1.0e-6;       /* funcube.c:65 */
+  float i_energy = 0, q_energy = 0, dotprod = 0;
+  float complex samp_sum = 0;
+  for (int i = 0; i < 2 * Blocksize; i += 2) {
+    float complex samp = CMPLXF(sampbuf[i], sampbuf[i + 1]) * SCALE16;
+    samp_sum += samp;
+    samp -= st->DC;
+    float re = crealf(samp), im = cimagf(samp);
+    i_energy += re * re;
+    q_energy += im * im;
+    re *= st->gain_i;
+    im *= st->gain_q;
+    dotprod += re * im;
+    im = st->secphi * im - st->tanphi * re;
+    sampbuf[i] = (int16_t)swap16((uint16_t)(signed short)round(re * SHRT_MAX));     /* htons, funcube.c:390-391 */
+    sampbuf[i + 1] = (int16_t)swap16((uint16_t)(signed short)round(im * SHRT_MAX));
+  }
+  st->DC += DC_alpha * (samp_sum - Blocksize * st->DC); /* funcube.c:417 */
+  float block_energy = i_energy + q_energy;
+  if (block_energy > 0) {
+    st->in_power = block_energy / Blocksize;
+    st->imbalance += rate_factor * ((i_energy / q_energy) - st->imbalance);
+    float dpn = 2 * dotprod / block_energy;
+    st->sinphi += rate_factor * (dpn - st->sinphi);
+    fe_update_gains(st);
+  }
+}
+static inline int fe_clip(float s, int lo, int hi) { /* "Clip?" (hackrf.c:518): an out-of-range float -> short conversion is
+  undefined in C; the restatement saturates, and the tests stay inside the range */
+  return s >= hi ? hi : s <= lo ? lo : (int)s;
+}
+float orc_hackrf_pack(int pt, const float *ip, const float *qp, int chunk, float Filter_atten, unsigned char *dp) {
+  float output_energy = 0;
+  for (int i = 0; i < chunk; i++) { /* hackrf.c:511-560 */
+    float s = *ip++ * Filter_atten;
+    output_energy += s * s;
+    float t = *qp++ * Filter_atten;
+    output_energy += t * t;
+    switch (pt) {
+    case 97: { /* IQ_PT: 16-bit little endian */
+      short si = (short)fe_clip(s, -32768, 32767), sq = (short)fe_clip(t, -32768, 32767);
+      dp[0] = si & 0xff; dp[1] = (si >> 8) & 0xff; dp[2] = sq & 0xff; dp[3] = (sq >> 8) & 0xff;
+      dp += 4;
+    } break;
+    case 95: { /* IQ_PT12: packed big endian */
+      short si = (short)fe_clip(s, -32768, 32767), sq = (short)fe_clip(t, -32768, 32767);
+      dp[0] = si >> 8;
+      dp[1] = (si & 0xf0) | ((sq >> 12) & 0xf);
+      dp[2] = sq >> 4;
+      dp += 3;
+    } break;
+    default: { /* IQ_PT8 */
+      dp[0] = (unsigned char)(signed char)fe_clip(s, -128, 127);
+      dp[1] = (unsigned char)(signed char)fe_clip(t, -128, 127);
+      dp += 2;
+    } break;
+    }
+  }
+  return output_energy;
+}
+
 /* =========================================================== misc.c */
 uint32_t orc_nextfastfft(uint32_t n) { /* misc.c:129-148 */
   uint64_t result = 4288306050ULL;

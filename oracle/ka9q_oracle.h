@@ -293,6 +293,24 @@ void orc_pl_init(struct orc_pl_session *sp);                                    
 void orc_pl_samples(struct orc_pl_session *sp, const int16_t *pcm_be, int n, struct orc_pl_result *pl, int maxpl,
                     int *npl, struct orc_dtmf_result *dt, int maxdt, int *ndt);
 
+/* ---------------------------------------------------------------- front-end corrections (hackrf.c, funcube.c) */
+struct orc_fe_state {             /* sdr->DC/sinphi/imbalance/clips/in_power and the file-scope gains of hackrf.c:136-139,815 */
+  float complex DC;
+  float sinphi, imbalance;
+  float gain_i, gain_q, secphi, tanphi;
+  int rotate_phase;
+  int clips;
+  float in_power;
+};
+void orc_fe_init(struct orc_fe_state *st, float imbalance0); /* gains 1,1,1,0; hackrf.c leaves imbalance at 0 */
+/* rx_callback, hackrf.c:822-919: `samples` int8 I/Q pairs -> the two float rails; Offset = rotate_phase increment */
+void orc_hackrf_rx_block(struct orc_fe_state *st, const int8_t *iq, int samples, int offset, float rate_factor,
+                         float *out_i, float *out_q);
+/* funcube.c:364-428: Blocksize int16 pairs in host order, corrected in place into network order */
+void orc_funcube_block(struct orc_fe_state *st, int16_t *sampbuf, int blocksize, float rate_factor);
+/* hackrf.c:511-560: decimated rails x Filter_atten -> IQ_PT (97, s16le) / IQ_PT12 (95) / IQ_PT8 (98); returns output_energy */
+float orc_hackrf_pack(int pt, const float *ip, const float *qp, int chunk, float filter_atten, unsigned char *out);
+
 /* ---------------------------------------------------------------- misc.c */
 uint32_t orc_nextfastfft(uint32_t n);                                                          /* misc.c:129 */
 

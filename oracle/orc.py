@@ -124,6 +124,12 @@ class DtmfResult(C.Structure):
                 ("high_snr", C.c_float)]
 
 
+class FeState(C.Structure):  # struct orc_fe_state
+    _fields_ = [("DC", Cf), ("sinphi", C.c_float), ("imbalance", C.c_float), ("gain_i", C.c_float), ("gain_q", C.c_float),
+                ("secphi", C.c_float), ("tanphi", C.c_float), ("rotate_phase", C.c_int), ("clips", C.c_int),
+                ("in_power", C.c_float)]
+
+
 class Notch(C.Structure):
     _fields_ = [("osc_phase", Cd), ("osc_step", Cd), ("dcstate", Cf), ("bw", C.c_float)]
 
@@ -224,6 +230,14 @@ def lib(fast=False):
     L.orc_afsk_init.argtypes = [vp]
     L.orc_afsk_init.restype = None
     L.orc_afsk_block.argtypes = [vp, vp, i, i, vp, i, vp, i, vp]
+    L.orc_fe_init.argtypes = [vp, f]
+    L.orc_fe_init.restype = None
+    L.orc_hackrf_rx_block.argtypes = [vp, vp, i, i, f, vp, vp]
+    L.orc_hackrf_rx_block.restype = None
+    L.orc_funcube_block.argtypes = [vp, vp, i, f]
+    L.orc_funcube_block.restype = None
+    L.orc_hackrf_pack.argtypes = [i, vp, vp, i, f, vp]
+    L.orc_hackrf_pack.restype = f
     L.orc_pl_init.argtypes = [vp]
     L.orc_pl_init.restype = None
     L.orc_pl_samples.argtypes = [vp, vp, i, vp, i, vp, vp, i, vp]
@@ -531,3 +545,42 @@ class PlSessionRunner:
         return ([dict(tone=r.tone, snr=r.snr, e0=r.e0, e1=r.e1, index=r.index) for r in pl[:npl.value]],
                 [dict(digit=chr(r.digit) if r.digit else "", low_index=r.low_index, high_index=r.high_index,
                       low_snr=r.low_snr, high_snr=r.high_snr) for r in dt[:ndt.value]])
+
+
+# ---------------------------------------------------------------- front-end corrections (hackrf.c, funcube.c)
+def fe_new(imbalance0=0.0, fast=False):
+    st = FeState()
+    lib(fast).orc_fe_init(C.addressof(st), imbalance0)
+    return st
+
+
+def fe_fields(st):
+    return dict(dc_re=st.DC.re, dc_im=st.DC.im, sinphi=st.sinphi, imbalance=st.imbalance, gain_i=st.gain_i, gain_q=st.gain_q,
+                secphi=st.secphi, tanphi=st.tanphi, rotate_phase=st.rotate_phase, clips=st.clips, in_power=st.in_power)
+
+
+def hackrf_rx(st, iq, samples, nblocks, offset, rate_factor, fast=False):
+    iq = np.ascontiguousarray(iq, np.int8)
+    oi, oq = np.empty(samples * nblocks, np.float32), np.empty(samples * nblocks, np.float32)
+    for b in range(nblocks):
+        seg = np.ascontiguousarray(iq[2 * b * samples:2 * (b + 1) * samples])
+        a, c = np.empty(samples, np.float32), np.empty(samples, np.float32)
+        lib(fast).orc_hackrf_rx_block(C.addressof(st), _vp(seg), samples, offset, rate_factor, _vp(a), _vp(c))
+        oi[b * samples:(b + 1) * samples], oq[b * samples:(b + 1) * samples] = a, c
+    return oi, oq
+
+
+def funcube_blocks(st, sampbuf, blocksize, nblocks, rate_factor, fast=False):
+    buf = np.ascontiguousarray(sampbuf, np.int16).copy()
+    for b in range(nblocks):
+        seg = np.ascontiguousarray(buf[2 * b * blocksize:2 * (b + 1) * blocksize])
+        lib(fast).orc_funcube_block(C.addressof(st), _vp(seg), blocksize, rate_factor)
+        buf[2 * b * blocksize:2 * (b + 1) * blocksize] = seg
+    return buf
+
+
+def hackrf_pack(pt, ip, qp, atten, fast=False):
+    ip, qp = np.ascontiguousarray(ip, np.float32), np.ascontiguousarray(qp, np.float32)
+    out = np.zeros(ip.size * {97: 4, 95: 3, 98: 2}[pt], np.uint8)
+    e = lib(fast).orc_hackrf_pack(pt, _vp(ip), _vp(qp), ip.size, atten, _vp(out))
+    return out, e
