@@ -124,12 +124,21 @@ def main():
     if args.gpus > 1 and world != args.gpus:
         print(f"bench.py: --gpus {args.gpus} needs torch.distributed.run with {args.gpus} ranks", file=sys.stderr)
         sys.exit(2)
+    # Rehearsal on a one-GPU box (not a measurement): KA9Q_BENCH_REHEARSE=1 puts every rank on device 0 and runs the
+    # collectives over gloo on host tensors, so that the N > 1 control flow can be exercised without N GPUs.
+    rehearse = os.environ.get("KA9Q_BENCH_REHEARSE", "0") == "1"
+    if rehearse:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
+    cdev = torch.device("cpu") if rehearse else device  # where collective operands live
     dist = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=device)
+        if rehearse:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=device)
 
     import pyka9q
     assert pyka9q.lib().ka9q_hip_init(local_rank) == 0, pyka9q.last_error()
@@ -166,7 +175,7 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     if dist is not None:
-        tt = torch.tensor([dt], device=device, dtype=torch.float64)
+        tt = torch.tensor([dt], device=cdev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
 
@@ -195,11 +204,11 @@ def main():
                 for _ in range(reps):
                     dist.broadcast(t, src=0)
                 torch.cuda.synchronize()
-                v = torch.tensor([(time.perf_counter() - tb) / reps], device=device, dtype=torch.float64)
+                v = torch.tensor([(time.perf_counter() - tb) / reps], device=cdev, dtype=torch.float64)
                 dist.all_reduce(v, op=dist.ReduceOp.MAX)
                 return round(1e3 * float(v.item()), 4)
-            raw_like = x if rank == 0 else torch.empty_like(x)
-            spec_like = torch.empty(T * N, 2, device=device, dtype=torch.float32)
+            raw_like = (x if rank == 0 else torch.empty_like(x)).to(cdev)
+            spec_like = torch.empty(T * N, 2, device=cdev, dtype=torch.float32)
             probe = {"broadcast_input_ms": bcast_ms(raw_like), "input_bytes": int(raw_like.numel() * 4),
                      "broadcast_spectrum_ms": bcast_ms(spec_like), "spectrum_bytes": int(spec_like.numel() * 4)}
             del spec_like
@@ -257,7 +266,7 @@ def main():
             "scaling": "weak",
             "vs_baseline": None,
             "dtype": "f32",
-            "data": "synthetic",
+            "data": "synthetic" if not rehearse else "synthetic (REHEARSAL: all ranks on one GPU, gloo; not a measurement)",
             "config": {"workload": "configs[1]: 8 MS/s cf32 wideband, L=131072 M=131073 N=262144, D=256 -> 31.25 kS/s, "
                                    "64 NBFM 12.5 kHz channels per GPU, 32 blocks (4.19 MS, 0.524 s of signal) per step",
                        "blocks_per_step": T, "channels_per_gpu": C, "sharding": "channels disjoint per GPU, FFT recomputed per GPU"},

@@ -29,9 +29,10 @@ __global__ __launch_bounds__(FE_NT) void kh_fe_moments(const void *__restrict__ 
   __shared__ long long red[FE_NT / 64][6];
   int const c = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
   long long m[6] = {0, 0, 0, 0, 0, 0};
+#pragma unroll
   for (int u = 0; u < FE_SPT; u++) {
     int const n = c * FE_CHUNK + u * FE_NT + tid;
-    if (n >= samples) break;
+    if (n >= samples) continue;
     size_t const idx = (size_t)b * samples + n;
     int i, q;
     if (WIDE) {
@@ -70,56 +71,72 @@ __global__ __launch_bounds__(FE_NT) void kh_fe_moments(const void *__restrict__ 
   }
 }
 
-// One thread: the chain of hackrf.c:906-917 / funcube.c:417-428 over the launch's blocks.  params[b] = what block b is
-// corrected with; *st is left as the reference leaves it after the last block.
-__global__ void kh_fe_chain(const long long *__restrict__ part, int nchunks, int nblocks, int samples, int funcube,
-                            int offset, float rate_factor, kh_fe_state *__restrict__ st, FeParams *__restrict__ params) {
-  if (threadIdx.x || blockIdx.x) return;
-  kh_fe_state s = *st;
+// The chain of hackrf.c:906-917 / funcube.c:417-428 over the launch's blocks.  One workgroup: all threads add up the
+// chunk partials of a tile of blocks into LDS, then thread 0 walks that tile's blocks in order.  params[b] = what block
+// b is corrected with; *st is left as the reference leaves it after the last block.
+constexpr int FE_TILE = 512;
+__global__ __launch_bounds__(FE_NT) void kh_fe_chain(const long long *__restrict__ part, int nchunks, int nblocks,
+                                                     int samples, int funcube, int offset, float rate_factor,
+                                                     kh_fe_state *__restrict__ st, FeParams *__restrict__ params) {
+  __shared__ long long tot[FE_TILE][6];
+  __shared__ kh_fe_state s;
+  if (threadIdx.x == 0) s = *st;
   double const S = funcube ? (double)(float)(1. / 32767) : (double)(float)(1. / 127); // SCALE16 / SCALE8 as floats
   float const DC_alpha = funcube ? 1.0e-6f : .001f;                                    // funcube.c:65, hackrf.c:66
-  for (int b = 0; b < nblocks; b++) {
-    FeParams p;
-    p.dc_re = s.dc_re;
-    p.dc_im = s.dc_im;
-    p.gain_i = s.gain_i;
-    p.gain_q = s.gain_q;
-    p.secphi = s.secphi;
-    p.tanphi = s.tanphi;
-    p.rotate_phase = s.rotate_phase;
-    p.pad = 0;
-    params[b] = p;
-    long long m[6] = {0, 0, 0, 0, 0, 0};
-    for (int c = 0; c < nchunks; c++)
-      for (int k = 0; k < 6; k++) m[k] += part[((size_t)b * nchunks + c) * 6 + k];
-    double const n = (double)samples, dr = s.dc_re, di = s.dc_im;
-    double const si = S * (double)m[0], sq = S * (double)m[1];
-    float const i_energy = (float)(S * S * (double)m[2] - 2.0 * dr * si + n * dr * dr);
-    float const q_energy = (float)(S * S * (double)m[3] - 2.0 * di * sq + n * di * di);
-    float const dotprod = (float)((double)s.gain_i * (double)s.gain_q * (S * S * (double)m[4] - di * si - dr * sq + n * dr * di));
-    s.clips += (int)m[5];
-    if (funcube) { // funcube.c:417
-      s.dc_re += DC_alpha * ((float)si - samples * s.dc_re);
-      s.dc_im += DC_alpha * ((float)sq - samples * s.dc_im);
-    } else {       // hackrf.c:906
-      s.dc_re += DC_alpha * ((float)si / samples - s.dc_re);
-      s.dc_im += DC_alpha * ((float)sq / samples - s.dc_im);
+  for (int b0 = 0; b0 < nblocks; b0 += FE_TILE) {
+    int const nb = nblocks - b0 < FE_TILE ? nblocks - b0 : FE_TILE;
+    __syncthreads();
+    for (int e = threadIdx.x; e < nb * 6; e += FE_NT) {
+      int const b = e / 6, k = e - 6 * b;
+      long long t = 0;
+      for (int c = 0; c < nchunks; c++) t += part[((size_t)(b0 + b) * nchunks + c) * 6 + k];
+      tot[b][k] = t;
     }
-    float const block_energy = i_energy + q_energy;
-    if (block_energy > 0) {
-      float const rf = funcube ? rate_factor : rate_factor * samples; // funcube.c:421 vs hackrf.c:910
-      s.in_power = block_energy / samples;
-      s.imbalance += rf * ((i_energy / q_energy) - s.imbalance);
-      float const dpn = 2 * dotprod / block_energy;
-      s.sinphi += rf * (dpn - s.sinphi);
-      s.gain_q = sqrtf((float)(0.5 * (double)(1 + s.imbalance)));
-      s.gain_i = sqrtf((float)(0.5 * (1 + 1. / (double)s.imbalance)));
-      s.secphi = 1 / sqrtf(1 - s.sinphi * s.sinphi);
-      s.tanphi = s.sinphi * s.secphi;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      for (int b = 0; b < nb; b++) {
+        FeParams p;
+        p.dc_re = s.dc_re;
+        p.dc_im = s.dc_im;
+        p.gain_i = s.gain_i;
+        p.gain_q = s.gain_q;
+        p.secphi = s.secphi;
+        p.tanphi = s.tanphi;
+        p.rotate_phase = s.rotate_phase;
+        p.pad = 0;
+        params[b0 + b] = p;
+        const long long *m = tot[b];
+        double const n = (double)samples, dr = s.dc_re, di = s.dc_im;
+        double const si = S * (double)m[0], sq = S * (double)m[1];
+        float const i_energy = (float)(S * S * (double)m[2] - 2.0 * dr * si + n * dr * dr);
+        float const q_energy = (float)(S * S * (double)m[3] - 2.0 * di * sq + n * di * di);
+        float const dotprod =
+            (float)((double)s.gain_i * (double)s.gain_q * (S * S * (double)m[4] - di * si - dr * sq + n * dr * di));
+        s.clips += (int)m[5];
+        if (funcube) { // funcube.c:417
+          s.dc_re += DC_alpha * ((float)si - samples * s.dc_re);
+          s.dc_im += DC_alpha * ((float)sq - samples * s.dc_im);
+        } else {       // hackrf.c:906
+          s.dc_re += DC_alpha * ((float)si / samples - s.dc_re);
+          s.dc_im += DC_alpha * ((float)sq / samples - s.dc_im);
+        }
+        float const block_energy = i_energy + q_energy;
+        if (block_energy > 0) {
+          float const rf = funcube ? rate_factor : rate_factor * samples; // funcube.c:421 vs hackrf.c:910
+          s.in_power = block_energy / samples;
+          s.imbalance += rf * ((i_energy / q_energy) - s.imbalance);
+          float const dpn = 2 * dotprod / block_energy;
+          s.sinphi += rf * (dpn - s.sinphi);
+          s.gain_q = sqrtf((float)(0.5 * (double)(1 + s.imbalance)));
+          s.gain_i = sqrtf((float)(0.5 * (1 + 1. / (double)s.imbalance)));
+          s.secphi = 1 / sqrtf(1 - s.sinphi * s.sinphi);
+          s.tanphi = s.sinphi * s.secphi;
+        }
+        s.rotate_phase = (s.rotate_phase + (int)(((long long)offset * samples) & 3)) & 3; // hackrf.c:897-898, per sample
+      }
     }
-    s.rotate_phase = (s.rotate_phase + (int)(((long long)offset * samples) & 3)) & 3; // hackrf.c:897-898, per sample
   }
-  *st = s;
+  if (threadIdx.x == 0) *st = s;
 }
 
 // algorithmic bytes: hackrf 2 in + 8 out per sample; funcube 4 in + 4 out
@@ -216,7 +233,7 @@ int launch_frontend(hipStream_t st, int funcube, const void *raw, int samples, i
     hipLaunchKernelGGL(kh_fe_moments<1>, gm, dim3(FE_NT), 0, st, raw, samples, nchunks, part);
   else
     hipLaunchKernelGGL(kh_fe_moments<0>, gm, dim3(FE_NT), 0, st, raw, samples, nchunks, part);
-  hipLaunchKernelGGL(kh_fe_chain, dim3(1), dim3(64), 0, st, part, nchunks, nblocks, samples, funcube, offset, rate_factor,
+  hipLaunchKernelGGL(kh_fe_chain, dim3(1), dim3(FE_NT), 0, st, part, nchunks, nblocks, samples, funcube, offset, rate_factor,
                      state, params);
   if (funcube)
     hipLaunchKernelGGL(kh_fe_apply<1>, ga, dim3(FE_NT), 0, st, raw, samples, offset, params, out_i, out_q,

@@ -86,8 +86,23 @@ __global__ __launch_bounds__(64) void kh_afsk_decode(const float2 *__restrict__ 
   kh_ax25_frame *fo = frames + (size_t)s * max_frames;
   kh_afsk_bit *bo = bits ? bits + (size_t)s * max_bits : nullptr;
   int nf = 0, nb = 0;
-  for (int n = 0; n < nsamp; n++) { // packet.c:440-544
-    float2 const v = ys[n];
+  // samples are fetched eight at a time, one group ahead: each lane walks its own row, and a load per sample would
+  // put a memory round trip into every step of the recurrence
+  constexpr int G = 8;
+  float2 nxt[G];
+#pragma unroll
+  for (int u = 0; u < G; u++) nxt[u] = u < nsamp ? ys[u] : make_float2(0.f, 0.f);
+  for (int n0 = 0; n0 < nsamp; n0 += G) {
+  float2 cur[G];
+#pragma unroll
+  for (int u = 0; u < G; u++) cur[u] = nxt[u];
+#pragma unroll
+  for (int u = 0; u < G; u++) nxt[u] = n0 + G + u < nsamp ? ys[n0 + G + u] : make_float2(0.f, 0.f);
+#pragma unroll
+  for (int u = 0; u < G; u++) { // packet.c:440-544
+    int const n = n0 + u;
+    if (n >= nsamp) break;
+    float2 const v = cur[u];
     float2 m = mul_cf_cd(v, mark); // filter->output.c[n] * step_osc(&mark): the phasor before the step
     oscp_step(mark);
     mark_acc.x += m.x;
@@ -157,6 +172,7 @@ __global__ __launch_bounds__(64) void kh_afsk_decode(const float2 *__restrict__ 
       }
     }
     last_val = cur_val;
+  }
   }
   st->mark_re = mark.re;
   st->mark_im = mark.im;
