@@ -1,6 +1,7 @@
 // kh_frontend.cpp -- host side of the front-end corrections and payload packing (hackrf.c, funcube.c).
 #include <hip/hip_runtime.h>
 #include <cstring>
+#include <mutex>
 #include <vector>
 
 #include "../../include/ka9q_hip.h"
@@ -38,6 +39,23 @@ struct DevBuf { // a device view of caller memory: the pointer itself, or a stag
   }
 };
 
+// Scratch of the calls below (block moments, per-block parameters, the state, energy partials): one device buffer
+// per process that only grows, so that a steady stream of calls allocates nothing.  Calls are serialised on it.
+std::mutex g_scratch_mutex;
+char *g_scratch = nullptr;
+size_t g_scratch_bytes = 0;
+char *scratch(size_t bytes) {
+  if (bytes <= g_scratch_bytes) return g_scratch;
+  if (g_scratch) hipFree(g_scratch);
+  g_scratch = nullptr;
+  g_scratch_bytes = 0;
+  size_t const want = (bytes + (1u << 20)) & ~(size_t)((1u << 20) - 1);
+  if (!KH_HIP(hipMalloc((void **)&g_scratch, want))) return nullptr;
+  g_scratch_bytes = want;
+  return g_scratch;
+}
+size_t up256(size_t v) { return (v + 255) & ~(size_t)255; }
+
 int correct(int funcube, struct kh_fe_state *state, void *raw, size_t in_bytes, unsigned samples, unsigned nblocks,
             int offset, float rate_factor, float *out_i, float *out_q) {
   if (!state || !raw || (!funcube && (!out_i || !out_q))) {
@@ -55,13 +73,14 @@ int correct(int funcube, struct kh_fe_state *state, void *raw, size_t in_bytes, 
   DevBuf in(raw, in_bytes, true, st);
   DevBuf oi(funcube ? raw : (void *)out_i, funcube ? 0 : total * sizeof(float), false, st);
   DevBuf oq(funcube ? raw : (void *)out_q, funcube ? 0 : total * sizeof(float), false, st);
-  long long *part = nullptr;
-  FeParams *params = nullptr;
-  kh_fe_state *dstate = nullptr;
-  bool ok = in.ok && oi.ok && oq.ok;
-  ok = ok && KH_HIP(hipMalloc((void **)&part, (size_t)nblocks * fe_chunks((int)samples) * 6 * sizeof(long long)));
-  ok = ok && KH_HIP(hipMalloc((void **)&params, nblocks * sizeof(FeParams)));
-  ok = ok && KH_HIP(hipMalloc((void **)&dstate, sizeof(kh_fe_state)));
+  std::lock_guard<std::mutex> lock(g_scratch_mutex);
+  size_t const part_bytes = up256((size_t)nblocks * fe_chunks((int)samples) * 6 * sizeof(long long));
+  size_t const par_bytes = up256(nblocks * sizeof(FeParams));
+  char *sc = scratch(part_bytes + par_bytes + 256);
+  long long *part = reinterpret_cast<long long *>(sc);
+  FeParams *params = reinterpret_cast<FeParams *>(sc + part_bytes);
+  kh_fe_state *dstate = reinterpret_cast<kh_fe_state *>(sc + part_bytes + par_bytes);
+  bool ok = in.ok && oi.ok && oq.ok && sc != nullptr;
   ok = ok && KH_HIP(hipMemcpyAsync(dstate, state, sizeof *state, hipMemcpyHostToDevice, st));
   // funcube corrects in place: every sample is read once by the apply kernel's own thread before it is overwritten
   ok = ok && launch_frontend(st, funcube, in.d, (int)samples, (int)nblocks, offset, rate_factor, dstate, part, params,
@@ -72,9 +91,6 @@ int correct(int funcube, struct kh_fe_state *state, void *raw, size_t in_bytes, 
   else
     ok = ok && oi.download(out_i, total * sizeof(float), st) && oq.download(out_q, total * sizeof(float), st);
   ok = ok && KH_HIP(hipStreamSynchronize(st));
-  if (part) hipFree(part);
-  if (params) hipFree(params);
-  if (dstate) hipFree(dstate);
   return ok ? 0 : -1;
 }
 } // namespace
@@ -111,14 +127,14 @@ int kh_hackrf_pack(int payload, const float *ip, const float *qp, unsigned int c
   hipStream_t st = default_stream();
   DevBuf di(ip, chunk * sizeof(float), true, st), dq(qp, chunk * sizeof(float), true, st), dout(out, chunk * bps, false, st);
   int const groups = fe_pack_groups((int)chunk);
-  float *epart = nullptr;
-  bool ok = di.ok && dq.ok && dout.ok && KH_HIP(hipMalloc((void **)&epart, groups * sizeof(float)));
+  std::lock_guard<std::mutex> lock(g_scratch_mutex);
+  float *epart = reinterpret_cast<float *>(scratch(groups * sizeof(float)));
+  bool ok = di.ok && dq.ok && dout.ok && epart != nullptr;
   ok = ok && launch_fe_pack(st, payload, (const float *)di.d, (const float *)dq.d, (int)chunk, filter_atten, dout.d, epart) == 0;
   std::vector<float> e(groups);
   ok = ok && KH_HIP(hipMemcpyAsync(e.data(), epart, groups * sizeof(float), hipMemcpyDeviceToHost, st));
   ok = ok && dout.download(out, chunk * bps, st);
   ok = ok && KH_HIP(hipStreamSynchronize(st));
-  if (epart) hipFree(epart);
   if (!ok) return -1;
   float total = 0.f;
   for (float v : e) total += v;

@@ -209,9 +209,8 @@ int launch_carry(hipStream_t st, const void *src, void *dst, size_t row_stride_b
 
 // ---------------------------------------------------------------- packet.c (kh_packet_kernels.hip, kh_packet.cpp)
 struct AfskState { // the locals of decode_task (packet.c:410-435) and sp->rtp_state_out, one per session
-  double mark_re, mark_im, space_re, space_im; // oscillator phasors (steps are launch constants)
-  int mark_steps, space_steps;
-  int symphase;
+  int symphase; // (the tone oscillators are a function of the session's sample count: kh_afsk_mix)
+  int pad;
   float2 mark_acc, space_acc, mark_off, space_off;
   float last_val, mid_val;
   int frame_bit, flagsync, ones;
@@ -221,9 +220,9 @@ struct AfskState { // the locals of decode_task (packet.c:410-435) and sp->rtp_s
 };
 int launch_afsk_ingest(hipStream_t st, const void *pcm_be, size_t pcm_stride, float *time, size_t time_stride, int hist,
                        int count, int nsess);
-int launch_afsk_decode(hipStream_t st, const float2 *y, size_t y_stride, int nsamp, int nsess, AfskState *states,
-                       void *frames, int max_frames, int *nframes, void *bits, int max_bits, int *nbits,
-                       unsigned long long sample_base);
+int launch_afsk_decode(hipStream_t st, const float2 *y, size_t y_stride, float4 *ms, size_t ms_stride, int nsamp, int nsess,
+                       AfskState *states, void *frames, int max_frames, int *nframes, void *bits, int max_bits,
+                       int *nbits, unsigned long long sample_base);
 
 // pl.c: tone tables and per-session carry between launches
 struct ToneTable {

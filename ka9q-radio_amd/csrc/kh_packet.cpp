@@ -4,7 +4,7 @@
 //   ntohs + scale into the REAL filter input        packet.c:340-348       kh_afsk_ingest
 //   execute_filter_input (REAL, L 1000, M 1049)     packet.c:325,345       kh_fft_fwd_lds<2048>
 //   execute_filter_output (COMPLEX, decimate 1)     packet.c:407-408,438   kh_filter_out
-//   AFSK correlators, Gardner timing, HDLC, CRC     packet.c:440-544       kh_afsk_decode
+//   AFSK correlators, Gardner timing, HDLC, CRC     packet.c:440-544       kh_afsk_mix, kh_afsk_decode
 // All state (overlap history, tone oscillators, bit clock, partial frame, RTP counters) stays on the device.
 #include <hip/hip_runtime.h>
 #include <algorithm>
@@ -26,6 +26,7 @@ struct kh_afsk {
   float *d_time[2] = {nullptr, nullptr}; // [S][time_stride]: M-1 history + T*L new samples
   float2 *d_spec = nullptr;    // [S][T*N] (N/2+1 bins used per block)
   float2 *d_y = nullptr;       // [S][T*L] analytic signal
+  float4 *d_ms = nullptr;      // [S][T*L] analytic signal x mark, x space phasors
   float2 *d_resp = nullptr;    // [S][N]
   ChanDesc *d_chans = nullptr; // [S]
   AfskState *d_state = nullptr;
@@ -44,7 +45,7 @@ extern "C" {
 int kh_afsk_destroy(kh_afsk *a) {
   if (!a) return 0;
   if (a->stream) hipStreamSynchronize(a->stream);
-  void *ptrs[] = {a->d_pcm, a->d_time[0], a->d_time[1], a->d_spec, a->d_y, a->d_resp, a->d_chans, a->d_state,
+  void *ptrs[] = {a->d_pcm, a->d_time[0], a->d_time[1], a->d_spec, a->d_y, a->d_ms, a->d_resp, a->d_chans, a->d_state,
                   a->d_frames, a->d_bits, a->d_nframes, a->d_nbits};
   for (void *p : ptrs)
     if (p) hipFree(p);
@@ -81,6 +82,7 @@ kh_afsk *kh_afsk_create(unsigned int sessions, unsigned int max_blocks, unsigned
   A(&a->d_time[1], S * a->time_stride * sizeof(float));
   A(&a->d_spec, S * a->spec_stride * sizeof(float2));
   A(&a->d_y, S * a->y_stride * sizeof(float2));
+  A(&a->d_ms, S * a->y_stride * sizeof(float4));
   A(&a->d_resp, S * N * sizeof(float2));
   A(&a->d_chans, S * sizeof(ChanDesc));
   A(&a->d_state, S * sizeof(AfskState));
@@ -102,11 +104,8 @@ kh_afsk *kh_afsk_create(unsigned int sessions, unsigned int max_blocks, unsigned
     std::vector<ChanDesc> ch(S);
     for (size_t s = 0; s < S; s++) ch[s] = ChanDesc{(int)s, 0, COMPLEX, 0};
     ok = KH_HIP(hipMemcpyAsync(a->d_chans, ch.data(), S * sizeof(ChanDesc), hipMemcpyHostToDevice, a->stream));
-    // memset(&mark, 0, ...) then set_osc: the phasor starts at 1 (packet.c:411-419; osc.c:24-27)
-    std::vector<AfskState> st(S);
-    memset(st.data(), 0, S * sizeof(AfskState));
-    for (auto &s : st) s.mark_re = s.space_re = 1.0;
-    ok = ok && KH_HIP(hipMemcpyAsync(a->d_state, st.data(), S * sizeof(AfskState), hipMemcpyHostToDevice, a->stream));
+    // d_state is all zeros, as decode_task's locals start (packet.c:422-435); the tone oscillators start at phasor 1
+    // with the session (packet.c:411-419; osc.c:24-27), i.e. they are exp(2 pi i f n) of the session's sample count
     ok = ok && KH_HIP(hipStreamSynchronize(a->stream));
   }
   if (!ok) {
@@ -183,7 +182,7 @@ int kh_afsk_execute(kh_afsk *a, unsigned int nblocks) {
     rc = launch_filter_output(st, a->d_spec, a->spec_stride, N, 1, a->d_chans, a->d_resp, N, L, a->d_y, a->y_stride,
                               (int)nblocks, a->S, FmFront{}, 1);
   if (!rc)
-    rc = launch_afsk_decode(st, a->d_y, a->y_stride, (int)need, a->S, a->d_state, a->d_frames, a->max_frames,
+    rc = launch_afsk_decode(st, a->d_y, a->y_stride, a->d_ms, a->y_stride, (int)need, a->S, a->d_state, a->d_frames, a->max_frames,
                             a->d_nframes, a->d_bits, a->max_bits, a->d_nbits, a->consumed);
   if (rc) return -1;
   a->cur ^= 1;
@@ -204,7 +203,7 @@ int kh_afsk_read_frames(kh_afsk *a, unsigned int session, struct kh_ax25_frame *
   if (!KH_HIP(hipMemcpyAsync(&cnt, a->d_nframes + session, sizeof(int), hipMemcpyDeviceToHost, a->stream)) ||
       !KH_HIP(hipStreamSynchronize(a->stream)))
     return -1;
-  size_t const take = std::min((size_t)cnt, max);
+  size_t const take = std::min(std::min((size_t)cnt, (size_t)a->max_frames), max);
   if (take && out &&
       (!KH_HIP(hipMemcpyAsync(out, a->d_frames + (size_t)session * a->max_frames, take * sizeof(kh_ax25_frame),
                               hipMemcpyDeviceToHost, a->stream)) ||

@@ -1,7 +1,8 @@
 // kh_packet_kernels.hip -- packet.c's receive side for many PCM sessions at once:
 //   kh_afsk_ingest   packet.c:340-348   network-order int16 -> float (with ntohs's unsigned result), into the REAL
 //                                       overlap-save time buffer of every session
-//   kh_afsk_decode   packet.c:437-545   mark/space correlators, Gardner timing, NRZI, HDLC unstuffing, crc_good
+//   kh_afsk_mix      packet.c:445,449   output x mark/space tone phasors, every sample in parallel
+//   kh_afsk_decode   packet.c:437-545   boxcar correlators, Gardner timing, NRZI, HDLC unstuffing, crc_good
 //                                       (ax25.c:140-156); one lane per session
 //   kh_tones_corr    pl.c:248-269       55 CTCSS + 8 DTMF tone correlators over one 50 ms interval per workgroup
 //   kh_tones_decide  pl.c:360-439       process_pl / process_dtmf per session
@@ -39,147 +40,179 @@ __device__ __forceinline__ int crc_good_dev(const unsigned char *frame, int leng
   return crc == 0xf0b8;
 }
 
-struct DOscP { // step_osc with rate == 0 (osc.c:39-50), phasor and step in fp64
-  double re, im, sre, sim;
-  int steps;
-};
-__device__ __forceinline__ void oscp_step(DOscP &o) {
-  double const nre = o.re * o.sre - o.im * o.sim;
-  double const nim = o.re * o.sim + o.im * o.sre;
-  o.re = nre;
-  o.im = nim;
-  if (++o.steps == 16384) { // Renorm_rate, osc.c:11,47-48,52-55
-    o.steps = 0;
-    double const m = hypot(o.re, o.im);
-    o.re /= m;
-    o.im /= m;
-  }
-}
-__device__ __forceinline__ float2 mul_cf_cd(float2 y, DOscP const &o) { // complex float x complex double -> complex float
-  double const yr = y.x, yi = y.y;
-  return make_float2((float)(yr * o.re - yi * o.im), (float)(yr * o.im + yi * o.re));
-}
 __device__ __forceinline__ float nrm(float2 v) { return v.x * v.x + v.y * v.y; } // cnrmf, dsp.h:65
 
-// One lane per session.  y: [nsess][y_stride] analytic signal, nsamp samples of this launch.  frames/bits are
-// per-session arrays of max_frames / max_bits records; their fill counts start at zero in every launch.
-__global__ __launch_bounds__(64) void kh_afsk_decode(const float2 *__restrict__ y, size_t y_stride, int nsamp, int nsess,
+// packet.c:445,449: s = filter->output.c[n] * step_osc(&mark|&space) for every sample of the launch, all of them at
+// once.  step_osc returns exp(2 pi i f n) for the n-th sample of the session (packet.c:410-419: both oscillators start
+// at 1 with the session); the phase is taken in closed form, frac(f n) in fp64, instead of by the recurrence.  The
+// product is complex float x complex double, rounded to float on assignment, as in the reference.
+// algorithmic bytes: 8 in + 16 out per sample.
+__global__ __launch_bounds__(256) void kh_afsk_mix(const float2 *__restrict__ y, size_t y_stride, float4 *__restrict__ ms,
+                                                   size_t ms_stride, int nsamp, double f_mark, double f_space,
+                                                   unsigned long long sample_base) {
+  int const s = blockIdx.y;
+  int const n = blockIdx.x * 256 + threadIdx.x;
+  if (n >= nsamp) return;
+  float2 const v = y[(size_t)s * y_stride + n];
+  double const dn = (double)(sample_base + (unsigned long long)n);
+  double pm = dn * f_mark, ps = dn * f_space;
+  pm -= floor(pm);
+  ps -= floor(ps);
+  double mre, mim, sre, sim;
+  sincospi(2.0 * pm, &mim, &mre);
+  sincospi(2.0 * ps, &sim, &sre);
+  double const yr = v.x, yi = v.y;
+  ms[(size_t)s * ms_stride + n] = make_float4((float)(yr * mre - yi * mim), (float)(yr * mim + yi * mre),
+                                              (float)(yr * sre - yi * sim), (float)(yr * sim + yi * sre));
+}
+
+// HDLC for one finished bit (packet.c:466-543 after the clock adjustment): NRZI, flags, bit unstuffing, CRC, frame out
+struct HdlcRegs {
+  int frame_bit, flagsync, ones;
+  unsigned out_ts, out_seq;
+  unsigned long long out_packets, out_bytes;
+  int nf;
+};
+__device__ __forceinline__ void hdlc_bit(HdlcRegs &h, bool transition, unsigned long long sample, unsigned char *hdlc,
+                                         kh_ax25_frame *fo, int max_frames) {
+  if (transition) { // NRZI zero
+    if (h.ones == 6) { // flag
+      if (h.flagsync) {
+        h.frame_bit -= 7;
+        int const bytes = h.frame_bit / 8;
+        // (the reference indexes hdlc_frame[1024] without a bound; longer frames are dropped here)
+        if (bytes > 0 && bytes <= KH_AX25_MAX && crc_good_dev(hdlc, bytes)) {
+          if (h.nf < max_frames) {
+            kh_ax25_frame *f = fo + h.nf;
+            f->sample = sample;
+            f->timestamp = h.out_ts;
+            f->seq = (uint16_t)h.out_seq;
+            f->bytes = (uint16_t)bytes;
+            for (int k = 0; k < KH_AX25_MAX; k++) f->data[k] = k < bytes ? hdlc[k] : 0;
+          }
+          h.nf++;
+          h.out_seq = (h.out_seq + 1) & 0xffff; // packet.c:498
+          h.out_ts += bytes;                    // packet.c:501
+          h.out_packets++;                      // packet.c:510-511
+          h.out_bytes += bytes;
+        }
+      }
+      for (int k = 0; k < KH_AX25_MAX / 4; k++) reinterpret_cast<unsigned *>(hdlc)[k] = 0; // packet.c:514-517
+      h.frame_bit = 0;
+      h.flagsync = 1;
+    } else if (h.ones == 5) {
+      // stuffed zero
+    } else if (h.ones < 5) {
+      if (h.flagsync) h.frame_bit++;
+    }
+    h.ones = 0;
+  } else { // NRZI one
+    if (++h.ones == 7) { // abort
+      for (int k = 0; k < KH_AX25_MAX / 4; k++) reinterpret_cast<unsigned *>(hdlc)[k] = 0;
+      h.frame_bit = 0;
+      h.flagsync = 0;
+    } else if (h.flagsync) {
+      if (h.frame_bit >= 0 && h.frame_bit / 8 < KH_AX25_MAX) hdlc[h.frame_bit / 8] |= (unsigned char)(1 << (h.frame_bit % 8));
+      h.frame_bit++;
+    }
+  }
+}
+
+// One lane per session; ms: the products of kh_afsk_mix.  What is serial per session is the bit clock: four complex
+// accumulators per sample, and at the end of a bit the Gardner step that moves the next bit's boundary
+// (packet.c:453-469).  Sessions are not aligned with each other, so in a wavefront of 64 some lane ends a bit at almost
+// every sample: that path is kept to the clock itself, and the bit (did the tone change, at which sample) goes into a
+// per-lane queue in LDS.  The HDLC state machine (packet.c:470-543) drains the queues once per 960 samples, all lanes
+// in step over their k-th queued bit -- the same bits in the same order as the reference sees them.
+constexpr int AFSK_DRAIN = 960, AFSK_QMAX = 32; // at most 960/39 + 1 = 25 bits end within 960 samples
+__global__ __launch_bounds__(64) void kh_afsk_decode(const float4 *__restrict__ ms, size_t ms_stride, int nsamp, int nsess,
                                                      AfskState *__restrict__ states, kh_ax25_frame *__restrict__ frames,
                                                      int max_frames, int *__restrict__ nframes,
                                                      kh_afsk_bit *__restrict__ bits, int max_bits, int *__restrict__ nbits,
-                                                     double mark_sre, double mark_sim, double space_sre,
-                                                     double space_sim, unsigned long long sample_base) {
-  int const s = blockIdx.x * 64 + threadIdx.x;
-  if (s >= nsess) return;
+                                                     unsigned long long sample_base, int spw) {
+  __shared__ unsigned queue[AFSK_QMAX][64];
+  int const lane = threadIdx.x;
+  // spw sessions per wavefront: what bounds this kernel is how many bytes its few wavefronts keep in flight, so with
+  // fewer sessions than the chip has lanes the sessions are spread over more wavefronts (the other lanes idle)
+  int const s0 = blockIdx.x * spw + lane;
+  bool const mine = lane < spw && s0 < nsess;
+  int const s = mine ? s0 : nsess - 1;
   constexpr int Samppbit = 40; // packet.c:52
   AfskState *st = states + s;
   unsigned char *hdlc = st->hdlc_frame;
-  DOscP mark{st->mark_re, st->mark_im, mark_sre, mark_sim, st->mark_steps};
-  DOscP space{st->space_re, st->space_im, space_sre, space_sim, st->space_steps};
   int symphase = st->symphase;
   float2 mark_acc = st->mark_acc, space_acc = st->space_acc, mark_off = st->mark_off, space_off = st->space_off;
   float last_val = st->last_val, mid_val = st->mid_val;
-  int frame_bit = st->frame_bit, flagsync = st->flagsync, ones = st->ones;
-  unsigned out_ts = st->out_timestamp, out_seq = st->out_seq;
-  unsigned long long out_packets = st->out_packets, out_bytes = st->out_bytes;
-  const float2 *ys = y + (size_t)s * y_stride;
+  HdlcRegs h{st->frame_bit, st->flagsync, st->ones, st->out_timestamp, st->out_seq, st->out_packets, st->out_bytes, 0};
+  const float4 *src = ms + (size_t)s * ms_stride;
   kh_ax25_frame *fo = frames + (size_t)s * max_frames;
   kh_afsk_bit *bo = bits ? bits + (size_t)s * max_bits : nullptr;
-  int nf = 0, nb = 0;
-  // samples are fetched eight at a time, one group ahead: each lane walks its own row, and a load per sample would
-  // put a memory round trip into every step of the recurrence
-  constexpr int G = 8;
-  float2 nxt[G];
+  int nb = 0, qn = 0;
+  auto drain = [&]() {
+    int qmax = qn;
 #pragma unroll
-  for (int u = 0; u < G; u++) nxt[u] = u < nsamp ? ys[u] : make_float2(0.f, 0.f);
+    for (int o = 32; o > 0; o >>= 1) qmax = max(qmax, __shfl_xor(qmax, o, 64));
+    for (int k = 0; k < qmax; k++)
+      if (k < qn && mine) {
+        unsigned const e = queue[k][lane];
+        hdlc_bit(h, e & 1u, sample_base + (e >> 1), hdlc, fo, max_frames);
+      }
+    qn = 0;
+  };
+  // Samples are fetched G at a time, one group ahead.  Each lane walks its own row, so a group costs one memory round
+  // trip (~1.6 us) however little work it holds: the group is as long as the register file allows (2 x 32 float4).
+  constexpr int G = 32;
+  static_assert(AFSK_DRAIN % G == 0, "queues are drained between groups");
+  if (!__builtin_amdgcn_ballot_w64(mine)) return;
+  float4 nxt[G];
+#pragma unroll
+  for (int u = 0; u < G; u++) nxt[u] = u < nsamp ? src[u] : make_float4(0.f, 0.f, 0.f, 0.f);
   for (int n0 = 0; n0 < nsamp; n0 += G) {
-  float2 cur[G];
+    if (n0 && n0 % AFSK_DRAIN == 0) drain();
+    float4 cur[G];
 #pragma unroll
-  for (int u = 0; u < G; u++) cur[u] = nxt[u];
+    for (int u = 0; u < G; u++) cur[u] = nxt[u];
 #pragma unroll
-  for (int u = 0; u < G; u++) nxt[u] = n0 + G + u < nsamp ? ys[n0 + G + u] : make_float2(0.f, 0.f);
+    for (int u = 0; u < G; u++) nxt[u] = n0 + G + u < nsamp ? src[n0 + G + u] : make_float4(0.f, 0.f, 0.f, 0.f);
+    // (without this fence the scheduler sinks each of those loads down to the sample that precedes its use and then
+    // waits for it: one memory round trip per sample)
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-  for (int u = 0; u < G; u++) { // packet.c:440-544
-    int const n = n0 + u;
-    if (n >= nsamp) break;
-    float2 const v = cur[u];
-    float2 m = mul_cf_cd(v, mark); // filter->output.c[n] * step_osc(&mark): the phasor before the step
-    oscp_step(mark);
-    mark_acc.x += m.x;
-    mark_acc.y += m.y;
-    mark_off.x += m.x;
-    mark_off.y += m.y;
-    m = mul_cf_cd(v, space);
-    oscp_step(space);
-    space_acc.x += m.x;
-    space_acc.y += m.y;
-    space_off.x += m.x;
-    space_off.y += m.y;
-    if (++symphase == Samppbit / 2) {
-      mid_val = nrm(mark_off) - nrm(space_off);
-      mark_off = space_off = make_float2(0.f, 0.f);
-    }
-    if (symphase < Samppbit) continue;
-    symphase = 0;
-    float const cur_val = nrm(mark_acc) - nrm(space_acc);
-    mark_acc = space_acc = make_float2(0.f, 0.f);
-    if (bo && nb < max_bits) {
-      bo[nb].sample = sample_base + n;
-      bo[nb].cur_val = cur_val;
-      bo[nb].reserved = 0;
-    }
-    nb++;
-    if (cur_val * last_val < 0) {
-      symphase += ((cur_val - last_val) * mid_val) > 0 ? +1 : -1; // packet.c:469
-      if (ones == 6) { // flag
-        if (flagsync) {
-          frame_bit -= 7;
-          int const bytes = frame_bit / 8;
-          // (the reference indexes hdlc_frame[1024] without a bound; longer frames are dropped here)
-          if (bytes > 0 && bytes <= KH_AX25_MAX && crc_good_dev(hdlc, bytes)) {
-            if (nf < max_frames) {
-              kh_ax25_frame *f = fo + nf;
-              f->sample = sample_base + n;
-              f->timestamp = out_ts;
-              f->seq = (uint16_t)out_seq;
-              f->bytes = (uint16_t)bytes;
-              for (int k = 0; k < KH_AX25_MAX; k++) f->data[k] = k < bytes ? hdlc[k] : 0;
-              nf++;
-            }
-            out_seq = (out_seq + 1) & 0xffff; // packet.c:498
-            out_ts += bytes;                  // packet.c:501
-            out_packets++;                    // packet.c:510-511
-            out_bytes += bytes;
-          }
-        }
-        for (int k = 0; k < KH_AX25_MAX / 4; k++) reinterpret_cast<unsigned *>(hdlc)[k] = 0; // packet.c:514-517
-        frame_bit = 0;
-        flagsync = 1;
-      } else if (ones == 5) {
-        // stuffed zero
-      } else if (ones < 5) {
-        if (flagsync) frame_bit++;
+    for (int u = 0; u < G; u++) { // packet.c:440-469
+      int const n = n0 + u;
+      if (n >= nsamp) break;
+      float4 const v = cur[u];
+      mark_acc.x += v.x;
+      mark_acc.y += v.y;
+      mark_off.x += v.x;
+      mark_off.y += v.y;
+      space_acc.x += v.z;
+      space_acc.y += v.w;
+      space_off.x += v.z;
+      space_off.y += v.w;
+      if (++symphase == Samppbit / 2) {
+        mid_val = nrm(mark_off) - nrm(space_off);
+        mark_off = space_off = make_float2(0.f, 0.f);
       }
-      ones = 0;
-    } else {
-      if (++ones == 7) { // abort
-        for (int k = 0; k < KH_AX25_MAX / 4; k++) reinterpret_cast<unsigned *>(hdlc)[k] = 0;
-        frame_bit = 0;
-        flagsync = 0;
-      } else if (flagsync) {
-        if (frame_bit >= 0 && frame_bit / 8 < KH_AX25_MAX) hdlc[frame_bit / 8] |= (unsigned char)(1 << (frame_bit % 8));
-        frame_bit++;
+      if (symphase < Samppbit) continue;
+      symphase = 0;
+      float const cur_val = nrm(mark_acc) - nrm(space_acc);
+      mark_acc = space_acc = make_float2(0.f, 0.f);
+      if (bo && nb < max_bits && mine) {
+        bo[nb].sample = sample_base + n;
+        bo[nb].cur_val = cur_val;
+        bo[nb].reserved = 0;
       }
+      nb++;
+      bool const transition = cur_val * last_val < 0;
+      if (transition) symphase += ((cur_val - last_val) * mid_val) > 0 ? +1 : -1; // packet.c:469
+      if (qn < AFSK_QMAX) queue[qn][lane] = ((unsigned)n << 1) | (transition ? 1u : 0u);
+      qn++;
+      last_val = cur_val;
     }
-    last_val = cur_val;
   }
-  }
-  st->mark_re = mark.re;
-  st->mark_im = mark.im;
-  st->mark_steps = mark.steps;
-  st->space_re = space.re;
-  st->space_im = space.im;
-  st->space_steps = space.steps;
+  drain();
+  if (!mine) return;
   st->symphase = symphase;
   st->mark_acc = mark_acc;
   st->space_acc = space_acc;
@@ -187,14 +220,14 @@ __global__ __launch_bounds__(64) void kh_afsk_decode(const float2 *__restrict__ 
   st->space_off = space_off;
   st->last_val = last_val;
   st->mid_val = mid_val;
-  st->frame_bit = frame_bit;
-  st->flagsync = flagsync;
-  st->ones = ones;
-  st->out_timestamp = out_ts;
-  st->out_seq = out_seq;
-  st->out_packets = out_packets;
-  st->out_bytes = out_bytes;
-  nframes[s] = nf;
+  st->frame_bit = h.frame_bit;
+  st->flagsync = h.flagsync;
+  st->ones = h.ones;
+  st->out_timestamp = h.out_ts;
+  st->out_seq = h.out_seq;
+  st->out_packets = h.out_packets;
+  st->out_bytes = h.out_bytes;
+  nframes[s] = h.nf;
   if (nbits) nbits[s] = nb;
 }
 
@@ -205,16 +238,23 @@ int launch_afsk_ingest(hipStream_t st, const void *pcm, size_t pcm_stride, float
                      static_cast<const uint16_t *>(pcm), pcm_stride, time, time_stride, hist, count);
   return KH_HIP(hipGetLastError()) ? 0 : -1;
 }
-int launch_afsk_decode(hipStream_t st, const float2 *y, size_t y_stride, int nsamp, int nsess, AfskState *states,
-                       void *frames, int max_frames, int *nframes, void *bits, int max_bits, int *nbits,
-                       unsigned long long sample_base) {
+int launch_afsk_decode(hipStream_t st, const float2 *y, size_t y_stride, float4 *ms, size_t ms_stride, int nsamp, int nsess,
+                       AfskState *states, void *frames, int max_frames, int *nframes, void *bits, int max_bits,
+                       int *nbits, unsigned long long sample_base) {
   if (nsamp <= 0 || nsess <= 0) return 0;
-  double msre, msim, ssre, ssim; // set_osc, osc.c:30: cispi(2 f), f = -1200/48000 and -2200/48000 (packet.c:414,419)
-  sincos(2 * (-1200. / 48000.f) * M_PI, &msim, &msre);
-  sincos(2 * (-2200. / 48000.f) * M_PI, &ssim, &ssre);
-  hipLaunchKernelGGL(kh_afsk_decode, dim3((nsess + 63) / 64), dim3(64), 0, st, y, y_stride, nsamp, nsess, states,
+  if (nsamp >= (1 << 30)) {
+    set_error("kh_afsk: more than 2^30 samples per session in one launch");
+    return -1;
+  }
+  // set_osc(&mark, -1200./Samprate, 0), set_osc(&space, -2200./Samprate, 0), packet.c:414,419 (Samprate is a float)
+  double const f_mark = -1200. / 48000.f, f_space = -2200. / 48000.f;
+  hipLaunchKernelGGL(kh_afsk_mix, dim3((nsamp + 255) / 256, nsess), dim3(256), 0, st, y, y_stride, ms, ms_stride, nsamp,
+                     f_mark, f_space, sample_base);
+  int spw = 64;
+  while (spw > 4 && (nsess + spw - 1) / spw < 2048) spw >>= 1; // aim at two wavefronts per SIMD (1024 SIMDs)
+  hipLaunchKernelGGL(kh_afsk_decode, dim3((nsess + spw - 1) / spw), dim3(64), 0, st, ms, ms_stride, nsamp, nsess, states,
                      static_cast<kh_ax25_frame *>(frames), max_frames, nframes, static_cast<kh_afsk_bit *>(bits), max_bits,
-                     nbits, msre, msim, ssre, ssim, sample_base);
+                     nbits, sample_base, spw);
   return KH_HIP(hipGetLastError()) ? 0 : -1;
 }
 
