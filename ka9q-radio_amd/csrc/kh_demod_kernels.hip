@@ -639,19 +639,52 @@ __device__ __forceinline__ void fm_finish_wave(FinishArgs const &F, int q, int l
       thr[j] = (up || n == 0 || n >= olen) ? INFINITY : la[j];
       if (n < olen) run = fmaxf(run, ang[j]);
     }
-    pdev_neg = __shfl(ang[0], 0, 64); // fm.c:97-98
-    // fm.c:101-102 is a chain through the block (on a typical signal every other sample moves pdev_neg), replayed
-    // literally: lanes in order, each running its K samples from the value the lane before left (wave-uniform, so
-    // it travels in a scalar register; no memory in the loop)
-    float cur = pdev_neg;
-    for (int l = 0; l < 64; l++) {
-      float c = cur;
+    float const c_first = __shfl(ang[0], 0, 64); // fm.c:97-98
+    // fm.c:101-102 is a chain through the block: pdev_neg = ang_n whenever lastaudio_n < pdev_neg (on a typical signal
+    // every other sample moves it).  Lane l maps the value entering its K samples to the value leaving them,
+    // g_l(c): for j < K: if (thr[j] < c) c = ang[j]; it hands c on unchanged when c <= min_j thr[j].  The values entering
+    // all 64 lanes are found by relaxation: start from "everything passes through", evaluate every g_l on its current
+    // guess (in parallel), and give lane l+1 the output of the nearest earlier lane that did not pass its input through
+    // (a segmented scan), until nothing changes.  A fixed point satisfies c_{l+1} = g_l(c_l) for every lane, i.e. it IS
+    // the serial result, sample for sample; after t rounds lanes 0..t are final, so 64 rounds bound it, and real
+    // signals settle in 3 to 14 (a replay lane by lane cost 64 x (2K + 2) instructions).
+    float mlane = INFINITY;
+#pragma unroll
+    for (int j = 0; j < K; j++) mlane = fminf(mlane, thr[j]);
+    float cin = c_first, last_val = c_first;
+    for (int it = 0; it < 64; it++) {
+      float c = cin;
 #pragma unroll
       for (int j = 0; j < K; j++)
         if (thr[j] < c) c = ang[j];
-      cur = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(c), l));
+      int has = !(cin <= mlane); // this lane's output is its own (not the input handed on)
+      int val = __float_as_int(c);
+      // inclusive scan over the 64 lanes of "the nearest lane at or before this one that has a value", in DPP moves
+      // (no LDS round trips): shifts by 1, 2, 4, 8 inside the rows of 16, then lane 15 of rows 0 and 2 into rows 1 and 3,
+      // then lane 31 into the upper half.  Lanes a move does not reach receive has = 0, the identity.
+#define KH_PDEV_STEP(CTRL, ROWS)                                                            \
+      {                                                                                       \
+        int const ph = __builtin_amdgcn_update_dpp(0, has, CTRL, ROWS, 0xf, false);           \
+        int const pv = __builtin_amdgcn_update_dpp(0, val, CTRL, ROWS, 0xf, false);           \
+        val = has ? val : pv;                                                                 \
+        has = has ? has : ph;                                                                 \
+      }
+      KH_PDEV_STEP(0x111, 0xf) // row_shr:1
+      KH_PDEV_STEP(0x112, 0xf) // row_shr:2
+      KH_PDEV_STEP(0x114, 0xf) // row_shr:4
+      KH_PDEV_STEP(0x118, 0xf) // row_shr:8
+      KH_PDEV_STEP(0x142, 0xa) // row_bcast:15 into rows 1, 3
+      KH_PDEV_STEP(0x143, 0xc) // row_bcast:31 into rows 2, 3
+#undef KH_PDEV_STEP
+      int const hp = __builtin_amdgcn_update_dpp(0, has, 0x138, 0xf, 0xf, false); // wave_shr:1 (lane 0 keeps 0)
+      int const np_ = __builtin_amdgcn_update_dpp(0, val, 0x138, 0xf, 0xf, false);
+      float const ncin = hp ? __int_as_float(np_) : c_first;
+      last_val = __builtin_amdgcn_readlane(has, 63) ? __int_as_float(__builtin_amdgcn_readlane(val, 63)) : c_first;
+      bool const changed = __float_as_int(ncin) != __float_as_int(cin);
+      cin = ncin;
+      if (!__builtin_amdgcn_ballot_w64(changed)) break;
     }
-    pdev_neg = cur;
+    pdev_neg = last_val;
   }
   if (lane == 0) {
     kh_status r;
