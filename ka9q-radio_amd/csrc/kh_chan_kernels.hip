@@ -105,7 +105,7 @@ __device__ __forceinline__ void chan_wave64_body(ChanArgs const &A, float2 *ex /
   static_assert(RA == 16, "64 lanes = RA rows x 4 splits");
   constexpr int RB = 64, ND = RA * RB, OLEN = ND / 2, K = OLEN / 64; // K = 8 samples per lane
   constexpr int PITCH = CW_PITCH; // in float2: rows start in different banks
-  constexpr int PITCH2 = K + 1;   // second transpose, in floats
+  constexpr int PITCH2 = K + 1;   // second transpose, in float2 (angle, weight)
   const float2 *__restrict__ spec = A.spec;
   const float2 *__restrict__ response = A.response;
   const float2 *__restrict__ tw = A.tw;
@@ -217,7 +217,7 @@ __device__ __forceinline__ void chan_wave64_body(ChanArgs const &A, float2 *ex /
       float2 const prev = lane ? rot : up;
       up = rot;
       float2 const p = cmulc(y[e], prev);
-      float a = atan2f(p.y, p.x);                                       // cargf, fm.c:89
+      float a = fast_atan2f(p.y, p.x);                                  // cargf, fm.c:89
       float w = __builtin_amdgcn_sqrtf(p.x * p.x + p.y * p.y) * inv_var; // cabsf(p) / fm_variance, fm.c:91
       if (w > 1) w = 1;
       if (e == 0 && lane == 0) a = 0.f, w = 0.f; // sample 0 needs the block before: kh_fm_finish
@@ -229,26 +229,20 @@ __device__ __forceinline__ void chan_wave64_body(ChanArgs const &A, float2 *ex /
   angsum = group_sum<64>(angsum);
 
   // ---- second transpose: lane l gets samples K l .. K l + K - 1
-  float *exf = reinterpret_cast<float *>(ex);
   float angc[K], wgtc[K];
   wave_sync();
 #pragma unroll
   for (int e = 0; e < K; e++) {
     int const n = lane + 64 * e;
-    exf[n + n / K] = ang[e];
+    ex[n + n / K] = make_float2(ang[e], wgt[e]);
   }
   wave_sync();
 #pragma unroll
-  for (int j = 0; j < K; j++) angc[j] = exf[lane * PITCH2 + j];
-  wave_sync();
-#pragma unroll
-  for (int e = 0; e < K; e++) {
-    int const n = lane + 64 * e;
-    exf[n + n / K] = wgt[e];
+  for (int j = 0; j < K; j++) {
+    float2 const aw = ex[lane * PITCH2 + j];
+    angc[j] = aw.x;
+    wgtc[j] = aw.y;
   }
-  wave_sync();
-#pragma unroll
-  for (int j = 0; j < K; j++) wgtc[j] = exf[lane * PITCH2 + j];
 
   // ---- fm.c:105-111 from a ZERO carry-in: s_n = (s_{n-1} * decay) + x_n; the block's carry-out goes to kh_fm_finish
   const DemodDesc *dd = fm.descs + ch;
@@ -261,21 +255,22 @@ __device__ __forceinline__ void chan_wave64_body(ChanArgs const &A, float2 *ex /
     for (int j = 0; j < K; j++) s0[j] = angc[j] * gain; // fm.c:105
   } else {
     double x[K];
-    double A = 1.0, B = 0.0; // this lane's chunk as the map carry_out = A*carry_in + B
+    double B = 0.0; // this lane's chunk as the map carry_out = decay^K * carry_in + B
 #pragma unroll
     for (int j = 0; j < K; j++) {
       x[j] = (double)angc[j] * .114 * (double)gain * (double)wgtc[j]; // fm.c:110
       B = (B + x[j]) * FM_DECAY;
-      A *= FM_DECAY;
     }
-    double Ai = A, Bi = B; // inclusive scan of the maps over the lanes
+    // inclusive scan of the maps over the lanes.  Every lane's A is the same constant decay^K, and a lane that takes part
+    // in the step at distance o has accumulated exactly o chunks, so its multiplier is decay^(K o): no A travels
+    double Bi = B;
+    double Apow = FM_DECAY_K8; // decay^(K o), squared from step to step
+    static_assert(K == 8, "FM_DECAY_K8 is decay^8");
 #pragma unroll
     for (int o = 1; o < 64; o <<= 1) {
-      double const Ap = __shfl_up(Ai, o, 64), Bp = __shfl_up(Bi, o, 64);
-      if (lane >= o) {
-        Bi = Ai * Bp + Bi;
-        Ai = Ai * Ap;
-      }
+      double const Bp = __shfl_up(Bi, o, 64);
+      if (lane >= o) Bi = fma(Apow, Bp, Bi);
+      Apow *= Apow;
     }
     double cin = __shfl_up(Bi, 1, 64); // carry into this lane's chunk for a zero carry into the block
     if (lane == 0) cin = 0.0;
