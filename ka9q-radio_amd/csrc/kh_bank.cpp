@@ -486,6 +486,7 @@ static int upload_channels(kh_bank *b) {
 // The kernel sequence of one execute call, in two halves.  Both run eagerly, or under stream capture when
 // kh_bank_execute builds the hipGraphs of this shape.
 // FRONT: convert + mix (radio.c:136-191) and the forward transform (filter.c:212-238) into slot b->sp.
+static bool n0_in_fft(const kh_bank *b);
 static int enqueue_front(kh_bank *b, hipStream_t st, unsigned int nblocks, bool prof) {
   int const L = b->cfg.L, M = b->cfg.M, N = b->N, P = b->P, sp = b->sp;
   size_t const need = (size_t)nblocks * L;
@@ -507,7 +508,9 @@ static int enqueue_front(kh_bank *b, hipStream_t st, unsigned int nblocks, bool 
   N0Plan const plan = n0_plan(N, b->cfg.samprate, b->cfg.n0_low, b->cfg.n0_high);
   bool const n0_on = b->cfg.compute_n0 && plan.valid;
   if (launch_forward_fft(st, time, b->time_stride, 0, b->d_spec[sp], b->d_tmp, b->spec_stride, N, L, nblocks, P,
-                         prof ? b->ev[2] : nullptr, N0Fuse{n0_on ? b->d_n0acc[sp] : nullptr, plan.start, plan.bincount},
+                         prof ? b->ev[2] : nullptr,
+                         N0Fuse{n0_on ? b->d_n0acc[sp] : nullptr, plan.start, plan.bincount,
+                                (n0_on && n0_in_fft(b)) ? b->d_n0acc[sp] + (size_t)P * nblocks * N0_SLOTS : nullptr},
                          fused ? &fi : nullptr))
     return -1;
   // overlap-save history for the next call (filter.c:230), into the other buffer
@@ -516,6 +519,10 @@ static int enqueue_front(kh_bank *b, hipStream_t st, unsigned int nblocks, bool 
     return -1;
   if (prof) hipEventRecord(b->ev[3], st);
   return 0;
+}
+static bool n0_in_fft(const kh_bank *b) {
+  static int const env = getenv("KA9Q_HIP_N0_IN_FFT") ? atoi(getenv("KA9Q_HIP_N0_IN_FFT")) : 1; // A/B switch
+  return env && b->cfg.compute_n0 && b->N <= KH_MAX_SMALL_N;
 }
 // BACK: compute_n0 (radio.c:422-465), per channel filter output (filter.c:240-384), demodulators, scaleclip.
 static int enqueue_back(kh_bank *b, hipStream_t st, unsigned int nblocks, bool prof) {
@@ -526,10 +533,12 @@ static int enqueue_back(kh_bank *b, hipStream_t st, unsigned int nblocks, bool p
   int const echunks = b->fused_now ? fused_ingest_tiles(N) : ingest_chunks(L);
   const float2 *n0spec = b->cfg.compute_n0 ? b->d_spec[sp] : nullptr;
   N0Pass1Args z;
-  bool const ride = b->ride_n0 && chan_wave_supported(b->ND, b->olen) &&
+  // (transforms that fit one workgroup have taken the second iteration themselves, from LDS: enqueue_front)
+  bool const in_fft = n0_in_fft(b);
+  bool const ride = !in_fft && b->ride_n0 && chan_wave_supported(b->ND, b->olen) &&
                     n0_pass1_args(&z, n0spec, b->spec_stride, N, plan, b->d_n0acc[sp], nblocks, P);
   if (!ride && launch_n0(st, n0spec, b->spec_stride, N, b->cfg.samprate, plan, b->d_energy[sp], echunks, L, b->d_n0state,
-                         b->d_n0acc[sp], b->d_istatus, nblocks, P))
+                         b->d_n0acc[sp], b->d_istatus, nblocks, P, in_fft ? 1 : 0))
     return -1;
   if (prof) hipEventRecord(b->ev[4], st);
   int taken = 0;

@@ -111,4 +111,22 @@ __device__ __forceinline__ void lds_fft(float2 *buf, const float2 *__restrict__ 
   FftPasses<R, W, NT, SI, SC, C_FAST, SIGN, R, 1>::run(buf, tw, tid);
 }
 
+// Strided tile accesses go through buffer instructions: ONE per-lane byte offset register serves every row of the
+// tile, the row offset (wave-uniform) travels in an SGPR.  With 64-bit flat addresses the compiler keeps one address
+// pair per outstanding load alive: 64 VGPRs for a 32-row column, which costs a workgroup per CU.
+typedef unsigned int kh_u32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void *base, unsigned bytes) { // base: wave-uniform
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(base), 0, bytes, 0x00020000);
+}
+__device__ __forceinline__ float2 buf_load2(__amdgpu_buffer_rsrc_t r, int voff, int soff) {
+  kh_u32x2 const t = __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, 0);
+  return make_float2(__uint_as_float(t.x), __uint_as_float(t.y));
+}
+__device__ __forceinline__ void buf_store2(float2 v, __amdgpu_buffer_rsrc_t r, int voff, int soff) {
+  kh_u32x2 t;
+  t.x = __float_as_uint(v.x);
+  t.y = __float_as_uint(v.y);
+  __builtin_amdgcn_raw_buffer_store_b64(t, r, voff, soff, 0);
+}
+
 } // namespace kh

@@ -35,6 +35,25 @@ __device__ __forceinline__ bool n0_bin_counts(int k, int N, N0Fuse const &n0) { 
   return d < n0.bincount;
 }
 
+// radio.c:451-462 on a spectrum that sits in LDS: sum and count of the counted bins below twice the first mean
+// (pw0 / bincount), left as slice 0 of kh_n0_final's 64 {sum, count} pairs for this (input, block); the other slices 0.
+template <int NT>
+__device__ __forceinline__ void n0_second_pass(const float2 *x, int N, N0Fuse const &n0, float pw0, float *p1, float *red) {
+  float const th = (pw0 / n0.bincount) * 2;
+  float s = 0.f, c = 0.f;
+  for (int k = threadIdx.x; k < N; k += NT) {
+    float2 const v = x[k];
+    float const p = v.x * v.x + v.y * v.y;
+    if (n0_bin_counts(k, N, n0) && p < th) {
+      s += p;
+      c += 1.f;
+    }
+  }
+  s = block_sum<NT>(s, red);
+  c = block_sum<NT>(c, red);
+  for (int k = threadIdx.x; k < 2 * 64; k += NT) p1[k] = k == 0 ? s : k == 1 ? c : 0.f;
+}
+
 template <int R, int NT>
 __global__ __launch_bounds__(NT) void kh_fft_fwd_lds(const void *__restrict__ time, size_t in_stride, int real_input,
                                                      float2 *__restrict__ spec, size_t spec_in_stride, int L,
@@ -68,7 +87,9 @@ __global__ __launch_bounds__(NT) void kh_fft_fwd_lds(const void *__restrict__ ti
   }
   if (n0.part != nullptr) { // uniform
     pw = block_sum<NT>(pw, red);
-    if (tid == 0) n0.part[((size_t)i * gridDim.x + b) * N0_SLOTS] = pw;
+    size_t const pt = (size_t)i * gridDim.x + b;
+    if (tid == 0) n0.part[pt * N0_SLOTS] = pw;
+    if (n0.part1 != nullptr) n0_second_pass<NT>(buf, R, n0, pw, n0.part1 + pt * (2 * 64), red);
   }
 }
 
@@ -99,7 +120,9 @@ __global__ __launch_bounds__(256) void kh_fft_fwd_any(const void *__restrict__ t
   }
   if (n0.part != nullptr) { // uniform
     pw = block_sum<256>(pw, red);
-    if (tid == 0) n0.part[((size_t)i * gridDim.x + b) * N0_SLOTS] = pw;
+    size_t const pt = (size_t)i * gridDim.x + b;
+    if (tid == 0) n0.part[pt * N0_SLOTS] = pw;
+    if (n0.part1 != nullptr) n0_second_pass<256>(res, R, n0, pw, n0.part1 + pt * (2 * 64), red);
   }
 }
 
@@ -129,23 +152,6 @@ __device__ __forceinline__ void inner_twiddle(float2 (&v)[RA], const float2 *__r
     v[4 * q + 2] = cmul(v[4 * q + 2], cmul(t, u2));
     v[4 * q + 3] = cmul(v[4 * q + 3], cmul(t, u3));
   }
-}
-// Strided tile accesses go through buffer instructions: ONE per-lane byte offset register serves every row of the
-// tile, the row offset (wave-uniform) travels in an SGPR.  With 64-bit flat addresses the compiler keeps one address
-// pair per outstanding load alive: 64 VGPRs for a 32-row column, which costs a workgroup per CU.
-typedef unsigned int kh_u32x2 __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void *base, unsigned bytes) { // base: wave-uniform
-  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(base), 0, bytes, 0x00020000);
-}
-__device__ __forceinline__ float2 buf_load2(__amdgpu_buffer_rsrc_t r, int voff, int soff) {
-  kh_u32x2 const t = __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, 0);
-  return make_float2(__uint_as_float(t.x), __uint_as_float(t.y));
-}
-__device__ __forceinline__ void buf_store2(float2 v, __amdgpu_buffer_rsrc_t r, int voff, int soff) {
-  kh_u32x2 t;
-  t.x = __float_as_uint(v.x);
-  t.y = __float_as_uint(v.y);
-  __builtin_amdgcn_raw_buffer_store_b64(t, r, voff, soff, 0);
 }
 __device__ __forceinline__ float2 big_tw(BigTwiddle const &bt, unsigned idx) { // W_N^idx, idx < N
   return cmul(bt.coarse[idx >> 10], bt.fine[idx & 1023]);
@@ -472,7 +478,9 @@ __global__ __launch_bounds__(NT, 4) void kh_fft_rows(const float2 *__restrict__ 
 template <int R>
 static int launch_small(hipStream_t st, const void *time, size_t in_stride, int real_input, float2 *spec,
                         size_t spec_in_stride, int L, int nblocks, int ninputs, N0Fuse n0) {
-  constexpr int NT = (R / 4 < 256) ? R / 4 : 256;
+  // two radix-4 butterflies per thread and pass at the large sizes: the block's 8 R bytes of LDS allow two workgroups
+  // per CU at R = 8192, and 256-thread workgroups left the CU at 8 wavefronts
+  constexpr int NT = (R / 4 < 256) ? R / 4 : (R >= 4096 ? R / 8 : 256);
   const float2 *tw = twiddle_table(R);
   if (!tw) return -1;
   hipLaunchKernelGGL((kh_fft_fwd_lds<R, NT>), dim3(nblocks, ninputs), dim3(NT), 0, st, time, in_stride, real_input, spec,

@@ -125,6 +125,10 @@ constexpr int N0_SLOTS = 64;
 struct N0Fuse {
   float *part;
   int start, bincount; // radio.c:440-447: bins (start + n) mod N, n < bincount
+  // N <= KH_MAX_SMALL_N only: the block's whole spectrum is in the workgroup's LDS, so the second iteration
+  // (radio.c:451-462: bins below twice the first mean) is taken there as well and the spectrum is never re-read.
+  // part1 = part + ninputs*nblocks*N0_SLOTS (kh_n0.cuh's layout: 2*64 floats per (input, block)); nullptr: not wanted.
+  float *part1 = nullptr;
 };
 int n0_partials(int N);
 // fi != nullptr (N > KH_MAX_SMALL_N only): the first pass reads the raw ring itself instead of `time` -- wire format
