@@ -558,6 +558,7 @@ int set_filter(struct filter_out *slave, float low, float high, float kaiser_bet
 }
 
 // ------------------------------------------------------------------ decimate.h
+// buf/outbuf/state pointers may be host or device memory (hipMemcpyDefault resolves the direction)
 static int decimate_host(struct hb15_state *hb15, float *hb3, int log_decimate, int stage_threshold, float *buf,
                          size_t rail_stride, int rails, int chunk, float *outbuf) {
   if (ensure_init()) return -1;
@@ -572,17 +573,17 @@ static int decimate_host(struct hb15_state *hb15, float *hb3, int log_decimate, 
   ok = ok && KH_HIP(hipMalloc(&dstate, nstate * sizeof(struct hb15_state)));
   ok = ok && KH_HIP(hipMalloc(&dhb3, nstate * sizeof(float)));
   for (int r = 0; r < rails && ok; r++)
-    ok = KH_HIP(hipMemcpyAsync(d + r * len, buf + r * rail_stride, len * sizeof(float), hipMemcpyHostToDevice, st));
-  if (ok && hb15) ok = KH_HIP(hipMemcpyAsync(dstate, hb15, nstate * sizeof(struct hb15_state), hipMemcpyHostToDevice, st));
-  if (ok && hb3) ok = KH_HIP(hipMemcpyAsync(dhb3, hb3, nstate * sizeof(float), hipMemcpyHostToDevice, st));
+    ok = KH_HIP(hipMemcpyAsync(d + r * len, buf + r * rail_stride, len * sizeof(float), hipMemcpyDefault, st));
+  if (ok && hb15) ok = KH_HIP(hipMemcpyAsync(dstate, hb15, nstate * sizeof(struct hb15_state), hipMemcpyDefault, st));
+  if (ok && hb3) ok = KH_HIP(hipMemcpyAsync(dhb3, hb3, nstate * sizeof(float), hipMemcpyDefault, st));
   int rc = ok ? launch_decimate(st, d, len, rails, chunk, log_decimate, stage_threshold, dstate, dhb3) : -1;
   for (int r = 0; r < rails && !rc; r++)
     rc = KH_HIP(hipMemcpyAsync((outbuf ? outbuf : buf) + r * rail_stride, d + r * len, chunk * sizeof(float),
-                               hipMemcpyDeviceToHost, st))
+                               hipMemcpyDefault, st))
              ? 0
              : -1;
-  if (!rc && hb15) rc = KH_HIP(hipMemcpyAsync(hb15, dstate, nstate * sizeof(struct hb15_state), hipMemcpyDeviceToHost, st)) ? 0 : -1;
-  if (!rc && hb3) rc = KH_HIP(hipMemcpyAsync(hb3, dhb3, nstate * sizeof(float), hipMemcpyDeviceToHost, st)) ? 0 : -1;
+  if (!rc && hb15) rc = KH_HIP(hipMemcpyAsync(hb15, dstate, nstate * sizeof(struct hb15_state), hipMemcpyDefault, st)) ? 0 : -1;
+  if (!rc && hb3) rc = KH_HIP(hipMemcpyAsync(hb3, dhb3, nstate * sizeof(float), hipMemcpyDefault, st)) ? 0 : -1;
   if (!rc) rc = KH_HIP(hipStreamSynchronize(st)) ? 0 : -1;
   if (d) hipFree(d);
   if (dstate) hipFree(dstate);
