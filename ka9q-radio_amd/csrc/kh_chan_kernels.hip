@@ -1,4 +1,4 @@
-// kh_chan_kernels.hip -- filter output for complex channels with N_dec = 1024 and olen = N_dec/2, wave-resident.
+// kh_chan_kernels.hip -- filter output for complex channels with N_dec = 1024 or 512 and olen = N_dec/2, wave-resident.
 //
 // Reference behaviour restated here (citations into the reference tree):
 //   execute_filter_output  filter.c:240-289 (complex -> complex bin select/rotate x response), 371-382 (CROSS_CONJ
@@ -89,7 +89,8 @@ struct ChanArgs {
   int nchan, npairs;
 };
 constexpr int CW_RA = 16, CW_PITCH = 64 + 1;    // rows of 64 complex points, pitch in float2
-constexpr int CW_LDS = CW_RA * CW_PITCH;        // float2 per wave
+constexpr int CW_LDS = 2 * CW_RA * (32 + 1);      // float2 per wave: two 32-lane pairs (1056) > one 64-lane pair (1040)
+static_assert(CW_LDS >= CW_RA * CW_PITCH, "both layouts fit");
 
 // the wave's barrier: LDS operations of one wave execute in order, so all that is needed between a transposing write
 // and its read is that the compiler keeps them apart (several of these waves share a workgroup with compute_n0's
@@ -100,11 +101,17 @@ __device__ __forceinline__ void wave_sync() {
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-template <int RA>
-__device__ __forceinline__ void chan_wave64_body(ChanArgs const &A, float2 *ex /*CW_LDS of this wave*/, int q, int lane) {
-  static_assert(RA == 16, "64 lanes = RA rows x 4 splits");
-  constexpr int RB = 64, ND = RA * RB, OLEN = ND / 2, K = OLEN / 64; // K = 8 samples per lane
-  constexpr int PITCH = CW_PITCH; // in float2: rows start in different banks
+// RB lanes own one (channel, block): RB = 64 (N_dec = 1024, one pair per wavefront) or RB = 32 (N_dec = 512, two pairs
+// per wavefront: the same channel's blocks b and b + 1, so that everything per channel stays wave-uniform).  `lane` is
+// the lane within the pair's group; `valid` is false for the padding pair of an odd block count, which computes on
+// block b (clamped by the caller) and stores nothing.
+template <int RA, int RB>
+__device__ __forceinline__ void chan_wave64_body(ChanArgs const &A, float2 *ex /*RA*(RB+1) float2 of this pair*/, int ch, int b,
+                                                 bool valid, int lane) {
+  static_assert(RA == 16 && (RB == 64 || RB == 32), "RB lanes = RA rows x RB/16 splits");
+  constexpr int ND = RA * RB, OLEN = ND / 2, K = OLEN / RB, SPLIT = RB / RA; // K = 8 samples per lane
+  static_assert(K == 8, "eight samples per lane");
+  constexpr int PITCH = RB + 1;   // in float2: rows start in different banks
   constexpr int PITCH2 = K + 1;   // second transpose, in float2 (angle, weight)
   const float2 *__restrict__ spec = A.spec;
   const float2 *__restrict__ response = A.response;
@@ -113,7 +120,7 @@ __device__ __forceinline__ void chan_wave64_body(ChanArgs const &A, float2 *ex /
   FmFront const &fm = A.fm;
   int const N = A.N, nchan = A.nchan;
   size_t const spec_in_stride = A.spec_in_stride, out_stride = A.out_stride;
-  int const ch = q % nchan, b = q / nchan;
+  (void)nchan;
   const ChanDesc *chans = A.chans;
   ChanDesc const cd = chans[ch];
   const float2 *fd = spec + (size_t)cd.input * spec_in_stride + (size_t)b * N;
@@ -156,10 +163,10 @@ __device__ __forceinline__ void chan_wave64_body(ChanArgs const &A, float2 *ex /
 
   // ---- stage B
   int const c = lane & (RA - 1), h = lane / RA;
-  float const sgn = (h & 1) ? -1.f : 1.f;                                  // i^{2h}
-  float const cr = h == 0 ? 1.f : h == 2 ? -1.f : 0.f, ci = h == 1 ? 1.f : h == 3 ? -1.f : 0.f; // i^h
   float2 u[16];
-  {
+  if constexpr (SPLIT == 4) {
+    float const sgn = (h & 1) ? -1.f : 1.f;                                  // i^{2h}
+    float const cr = h == 0 ? 1.f : h == 2 ? -1.f : 0.f, ci = h == 1 ? 1.f : h == 3 ? -1.f : 0.f; // i^h
     const float2 *row = ex + c * PITCH;
 #pragma unroll
     for (int j = 0; j < 16; j++) {
@@ -168,18 +175,26 @@ __device__ __forceinline__ void chan_wave64_body(ChanArgs const &A, float2 *ex /
       float2 const t = make_float2(fmaf(sgn, z3.x, z1.x), fmaf(sgn, z3.y, z1.y)); // z1 + i^{2h} z3
       u[j] = make_float2(s.x + cr * t.x - ci * t.y, s.y + cr * t.y + ci * t.x);   // + i^h (...)
     }
+  } else { // two-way split of the 32-point row: u[j] = z[j] + (-1)^h z[j + 16]
+    float const sgn = h ? -1.f : 1.f;
+    const float2 *row = ex + c * PITCH;
+#pragma unroll
+    for (int j = 0; j < 16; j++) {
+      float2 const z0 = row[j], z1 = row[j + 16];
+      u[j] = make_float2(fmaf(sgn, z1.x, z0.x), fmaf(sgn, z1.y, z0.y));
+    }
   }
-  chan_twiddle_strided<16, +1, ND / 64>(u, tw, h); // u[j] *= W_64^{j h}
+  chan_twiddle_strided<16, +1, ND / RB>(u, tw, h); // u[j] *= W_RB^{j h}
   reg_fft<16, +1>(u);
-  float2 y[K]; // sample n' = lane + 64 e of the block (filter.c:197,206: the last OLEN points)
+  float2 y[K]; // sample n' = lane + RB e of the block (filter.c:197,206: the last OLEN points)
 #pragma unroll
   for (int e = 0; e < K; e++) y[e] = u[8 + e];
 
   bool const is_fm = fm.stat != nullptr && cd.fm_stats; // uniform over the wave
-  if (!is_fm || fm.write_baseband) {
+  if ((!is_fm || fm.write_baseband) && valid) {
     float2 *o = out + (size_t)ch * out_stride + (size_t)b * OLEN;
 #pragma unroll
-    for (int e = 0; e < K; e++) o[lane + 64 * e] = y[e];
+    for (int e = 0; e < K; e++) o[lane + RB * e] = y[e];
   }
   if (!is_fm) return;
 
@@ -193,27 +208,36 @@ __device__ __forceinline__ void chan_wave64_body(ChanArgs const &A, float2 *ex /
     amp[e] = __builtin_amdgcn_sqrtf(t);
     sa += amp[e];
   }
-  bb = group_sum<64>(bb);
-  sa = group_sum<64>(sa);
+  bb = group_sum<RB>(bb);
+  sa = group_sum<RB>(sa);
   float const avg = sa / OLEN;
   float var = 0.f;
 #pragma unroll
   for (int e = 0; e < K; e++) var += (amp[e] - avg) * (amp[e] - avg);
-  var = group_sum<64>(var) / (OLEN - 1);
-  float const snr = fmaxf(0.0f, (float)fm_snr((double)(avg * avg / var)));
-  float2 const first = make_float2(__shfl(y[0].x, 0, 64), __shfl(y[0].y, 0, 64));
-  float2 const last = make_float2(__shfl(y[K - 1].x, 63, 64), __shfl(y[K - 1].y, 63, 64));
+  var = group_sum<RB>(var) / (OLEN - 1);
+  float snr;
+  if constexpr (RB == 64) {
+    snr = fmaxf(0.0f, (float)fm_snr((double)(avg * avg / var)));
+  } else { // fm_snr wants a wave-uniform argument: one call per half
+    float const r = avg * avg / var;
+    float const r0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(r), 0));
+    float const r1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(r), 32));
+    float const s0_ = fmaxf(0.0f, (float)fm_snr((double)r0)), s1_ = fmaxf(0.0f, (float)fm_snr((double)r1));
+    snr = (threadIdx.x & 32) ? s1_ : s0_;
+  }
+  float2 const first = make_float2(__shfl(y[0].x, 0, RB), __shfl(y[0].y, 0, RB));
+  float2 const last = make_float2(__shfl(y[K - 1].x, RB - 1, RB), __shfl(y[K - 1].y, RB - 1, RB));
 
   // ---- fm.c:85-93 for samples 1 .. OLEN-1: p = y[n] conj(y[n-1]); n-1 sits in lane-1 (lane 0: lane 63, one row up)
   float ang[K], wgt[K];
   float angsum = 0.f;
   {
     float const inv_var = 1.f / var;
-    int const src = (lane + 63) & 63;
+    int const src = (lane + RB - 1) & (RB - 1);
     float2 up = make_float2(0.f, 0.f);
 #pragma unroll
     for (int e = 0; e < K; e++) {
-      float2 const rot = make_float2(__shfl(y[e].x, src, 64), __shfl(y[e].y, src, 64));
+      float2 const rot = make_float2(__shfl(y[e].x, src, RB), __shfl(y[e].y, src, RB));
       float2 const prev = lane ? rot : up;
       up = rot;
       float2 const p = cmulc(y[e], prev);
@@ -226,14 +250,14 @@ __device__ __forceinline__ void chan_wave64_body(ChanArgs const &A, float2 *ex /
       angsum += a;
     }
   }
-  angsum = group_sum<64>(angsum);
+  angsum = group_sum<RB>(angsum);
 
   // ---- second transpose: lane l gets samples K l .. K l + K - 1
   float angc[K], wgtc[K];
   wave_sync();
 #pragma unroll
   for (int e = 0; e < K; e++) {
-    int const n = lane + 64 * e;
+    int const n = lane + RB * e;
     ex[n + n / K] = make_float2(ang[e], wgt[e]);
   }
   wave_sync();
@@ -267,14 +291,14 @@ __device__ __forceinline__ void chan_wave64_body(ChanArgs const &A, float2 *ex /
     double Apow = FM_DECAY_K8; // decay^(K o), squared from step to step
     static_assert(K == 8, "FM_DECAY_K8 is decay^8");
 #pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-      double const Bp = __shfl_up(Bi, o, 64);
+    for (int o = 1; o < RB; o <<= 1) {
+      double const Bp = __shfl_up(Bi, o, RB);
       if (lane >= o) Bi = fma(Apow, Bp, Bi);
       Apow *= Apow;
     }
-    double cin = __shfl_up(Bi, 1, 64); // carry into this lane's chunk for a zero carry into the block
+    double cin = __shfl_up(Bi, 1, RB); // carry into this lane's chunk for a zero carry into the block
     if (lane == 0) cin = 0.0;
-    carry_out = __shfl(Bi, 63, 64);
+    carry_out = __shfl(Bi, RB - 1, RB);
 #pragma unroll
     for (int j = 0; j < K; j++) {
       cin += x[j];     // samples[n] = lastaudio += ...
@@ -282,6 +306,7 @@ __device__ __forceinline__ void chan_wave64_body(ChanArgs const &A, float2 *ex /
       cin *= FM_DECAY; // lastaudio *= 0.99376949
     }
   }
+  if (!valid) return;
   size_t const rec = (size_t)ch * fm.stat_stride + b;
   float4 *wo = reinterpret_cast<float4 *>(fm.work + (size_t)ch * fm.work_stride + (size_t)b * OLEN + (size_t)lane * K);
 #pragma unroll
@@ -293,30 +318,61 @@ __device__ __forceinline__ void chan_wave64_body(ChanArgs const &A, float2 *ex /
 }
 
 
-// one wavefront per workgroup (filter.h API path, and banks without compute_n0)
-__global__ __launch_bounds__(64) void kh_chan_wave64(ChanArgs A) {
-  __shared__ float2 ex[CW_LDS];
-  chan_wave64_body<CW_RA>(A, ex, blockIdx.x, threadIdx.x);
+// pairs of one wavefront: RB = 64: pair w; RB = 32: the two halves take blocks 2 j and 2 j + 1 of the same channel
+template <int RB>
+__device__ __forceinline__ void chan_wave_dispatch(ChanArgs const &A, float2 *ex_wave, int w, int nblocks, int lane64) {
+  constexpr int PAIR_LDS = CW_RA * (RB + 1);
+  if constexpr (RB == 64) {
+    chan_wave64_body<CW_RA, 64>(A, ex_wave, w % A.nchan, w / A.nchan, true, lane64);
+  } else {
+    int const half = lane64 >> 5;
+    int const ch = w % A.nchan, b = 2 * (w / A.nchan) + half;
+    chan_wave64_body<CW_RA, 32>(A, ex_wave + half * PAIR_LDS, ch, b < nblocks ? b : nblocks - 1, b < nblocks, lane64 & 31);
+  }
+}
+template <int RB>
+__host__ __device__ constexpr int chan_waves(int nchan, int nblocks) { // wavefronts of a launch
+  return RB == 64 ? nchan * nblocks : nchan * ((nblocks + 1) / 2);
 }
 
-// Horizontal fusion for the bank: workgroups [0, nchan_wg) carry BACK_WAVES (channel, block) wavefronts each, the rest are
+// one wavefront per workgroup (filter.h API path, and banks without compute_n0)
+template <int RB>
+__global__ __launch_bounds__(64) void kh_chan_wave64(ChanArgs A, int nblocks) {
+  __shared__ float2 ex[CW_LDS];
+  chan_wave_dispatch<RB>(A, ex, blockIdx.x, nblocks, threadIdx.x);
+}
+
+// Horizontal fusion for the bank: workgroups [0, nchan_wg) carry BACK_WAVES channel wavefronts each, the rest are
 // compute_n0's second iteration (radio.c:451-462, kh_n0.cuh) over N0_GX slices per (input, block).  The channel
 // waves wait on memory latency and use little bandwidth, the n0 workgroups stream the spectrum: in one launch they
 // share the chip instead of queueing behind one another.
 constexpr int BACK_WAVES = 2; // channel wavefronts per workgroup: their LDS sets how many workgroups of either kind a CU holds
-__global__ __launch_bounds__(64 * BACK_WAVES) void kh_back_a(ChanArgs A, N0Pass1Args Z, int nchan_wg) {
+template <int RB>
+__global__ __launch_bounds__(64 * BACK_WAVES) void kh_back_a(ChanArgs A, N0Pass1Args Z, int nchan_wg, int nblocks, int nwaves) {
   __shared__ float2 ex[BACK_WAVES * CW_LDS];
   if ((int)blockIdx.x < nchan_wg) {
     int const wave = threadIdx.x >> 6;
-    int const q = blockIdx.x * BACK_WAVES + wave;
-    if (q < A.npairs) chan_wave64_body<CW_RA>(A, ex + wave * CW_LDS, q, threadIdx.x & 63);
+    int const w = blockIdx.x * BACK_WAVES + wave;
+    if (w < nwaves) chan_wave_dispatch<RB>(A, ex + wave * CW_LDS, w, nblocks, threadIdx.x & 63);
   } else {
     n0_pass1_body(Z, blockIdx.x - nchan_wg, reinterpret_cast<float *>(ex));
   }
 }
 
-// R*R == ND; 0 if this shape has no wave-resident kernel (the caller falls back to kh_filter_out)
-int chan_wave_supported(int ND, int olen) { return ND == 1024 && olen * 2 == ND; }
+// 0 if this shape has no wave-resident kernel (the caller falls back to kh_filter_out)
+int chan_wave_supported(int ND, int olen) { return (ND == 1024 || ND == 512) && olen * 2 == ND; }
+
+template <int RB>
+static void launch_chan_wave_rb(hipStream_t st, ChanArgs const &A, int nblocks, const N0Pass1Args *n0) {
+  int const nwaves = chan_waves<RB>(A.nchan, nblocks);
+  if (n0) {
+    int const nchan_wg = (nwaves + BACK_WAVES - 1) / BACK_WAVES;
+    hipLaunchKernelGGL(kh_back_a<RB>, dim3(nchan_wg + n0->gx * n0->nblocks * n0->ninputs), dim3(64 * BACK_WAVES), 0, st, A, *n0,
+                       nchan_wg, nblocks, nwaves);
+  } else {
+    hipLaunchKernelGGL(kh_chan_wave64<RB>, dim3(nwaves), dim3(64), 0, st, A, nblocks);
+  }
+}
 
 int launch_chan_wave(hipStream_t st, const float2 *spec, size_t spec_in_stride, int N, const ChanDesc *chans,
                      const float2 *response, int ND, int olen, float2 *out, size_t out_stride, int nblocks, int nchan,
@@ -330,13 +386,10 @@ int launch_chan_wave(hipStream_t st, const float2 *spec, size_t spec_in_stride, 
   if (!tw) return -1;
   int const npairs = nchan * nblocks;
   ChanArgs const A{spec, spec_in_stride, N, chans, response, out, out_stride, tw, fm, nchan, npairs};
-  if (n0) {
-    int const nchan_wg = (npairs + BACK_WAVES - 1) / BACK_WAVES;
-    hipLaunchKernelGGL(kh_back_a, dim3(nchan_wg + n0->gx * n0->nblocks * n0->ninputs), dim3(64 * BACK_WAVES), 0, st, A, *n0,
-                       nchan_wg);
-  } else {
-    hipLaunchKernelGGL(kh_chan_wave64, dim3(npairs), dim3(64), 0, st, A);
-  }
+  if (ND == 1024)
+    launch_chan_wave_rb<64>(st, A, nblocks, n0);
+  else
+    launch_chan_wave_rb<32>(st, A, nblocks, n0);
   return KH_HIP(hipGetLastError()) ? 0 : -1;
 }
 

@@ -91,6 +91,17 @@ def test_fm_bank_8MSps(hip):
     assert all(abs(r[3]["pdeviation"] - 2500) < 150 for r in opened)
 
 
+def test_fm_bank_ndec512_odd_block_counts(hip):
+    """N_dec = 512 / olen = 256 (config 4's channel shape at a small N): two blocks of a channel share a wavefront in the
+    channel kernel, so odd block counts leave a padding half; compute_n0 rides in the same launch."""
+    fs, L, M, D = 1_000_000, 8192, 8193, 32
+    N = L + M - 1
+    sigs = [(-2, 0.05, 400.0, 2500.0), (0, 0.02, 700.0, 2000.0), (3, 0.1, 1000.0, 3000.0)]
+    for T, calls in ((3, 2), (1, 3), (4, 1)):
+        x = synth.wideband_fm(0, T * calls * L, fs, N, sigs)
+        _run_pair(hip, L, M, D, fs, sigs + [(7, 0, 0, 0)], x, T, calls, n0=True)
+
+
 def test_fm_bank_192k_flat_and_deemph(hip):
     """config 1 shape (192 kS/s, L=3840, M=4353, N=8192, D=4): single-workgroup FFT path, olen = 960."""
     fs, L, M, D = 192_000, 3840, 4353, 4

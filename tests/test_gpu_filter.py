@@ -59,11 +59,13 @@ def test_rotate_indexing_bit_exact(hip, rotate):
 
 @pytest.mark.parametrize("out_type", [orc.COMPLEX, orc.CROSS_CONJ])
 @pytest.mark.parametrize("rotate", [0, 3, -700, 16383, -16383, 16384 - 512, 511 - 16384])
-def test_wave_resident_output_rotate_and_cross_conj(hip, out_type, rotate):
-    """N_dec = 1024 with olen = 512 takes the wave-resident kernel (kh_chan_kernels.hip): the same index arithmetic
-    (filter.c:274-289, including rotations that wrap around N in the middle of the channel) and the CROSS_CONJ fold
-    (filter.c:371-381), which that kernel does while loading."""
-    L, M, D = 8192, 8193, 16
+@pytest.mark.parametrize("D", [16, 32])
+def test_wave_resident_output_rotate_and_cross_conj(hip, out_type, rotate, D):
+    """N_dec = 1024 / olen = 512 (D = 16: one wavefront per block) and N_dec = 512 / olen = 256 (D = 32: half a
+    wavefront per block, here with the other half idle) take the wave-resident kernel (kh_chan_kernels.hip): the same
+    index arithmetic (filter.c:274-289, including rotations that wrap around N in the middle of the channel) and the
+    CROSS_CONJ fold (filter.c:371-381), which that kernel does while loading."""
+    L, M = 8192, 8193
     g = hip.Filter(L, M, D, orc.COMPLEX, out_type)
     o = orc.Filter(L, M, D, orc.COMPLEX, out_type)
     g.set_filter(-0.2, 0.31, 3.0)
