@@ -63,8 +63,11 @@ struct kh_bank {
   // front hands to the back is double buffered (sp = slot of the current launch), so the front of launch k+1 runs
   // beside the back of launch k.
   hipStream_t front = nullptr;
-  hipEvent_t ev_front_done[2] = {}, ev_back_done[2] = {};
+  static constexpr int MAX_SLOTS = 4;
+  hipEvent_t ev_front_done[MAX_SLOTS] = {}, ev_back_done[MAX_SLOTS] = {};
   int sp = 0, last_sp = 0, pipeline = 1;
+  std::vector<IngestDesc> idesc_dev; // what d_idesc holds
+  int nslots = 3; // ring depth of what the front half hands to the back half (KA9Q_HIP_SLOTS, 2..4)
   int fused_ingest = 1;   // policy (KA9Q_HIP_FUSED_INGEST)
   int ride_n0 = 1;        // policy (KA9Q_HIP_RIDE_N0)
   bool fused_now = false; // this launch: large transform and no oscillator active
@@ -74,7 +77,7 @@ struct kh_bank {
   float2 *d_time[2] = {nullptr, nullptr};
   size_t time_stride = 0; // samples per input: (M-1) + T*L (+pad)
   int cur = 0;
-  float2 *d_spec[2] = {}, *d_tmp = nullptr;
+  float2 *d_spec[MAX_SLOTS] = {}, *d_tmp = nullptr;
   size_t spec_stride = 0; // T*N
   ChanDesc *d_chans = nullptr;
   float2 *d_resp = nullptr;
@@ -92,7 +95,7 @@ struct kh_bank {
   size_t pcm_stride = 0; // 2*T*olen
   kh_status *d_status = nullptr;
   kh_input_status *d_istatus = nullptr;
-  float *d_energy[2] = {}, *d_n0acc[2] = {}, *d_n0state = nullptr, *d_scalar = nullptr;
+  float *d_energy[MAX_SLOTS] = {}, *d_n0acc[MAX_SLOTS] = {}, *d_n0state = nullptr, *d_scalar = nullptr;
   int *d_lists = nullptr; // fm | linear | am, C entries each
   FmBlockStat *d_fmstat = nullptr; // FM path scratch (kh_internal.h)
   FmWork *d_fmwork = nullptr;
@@ -151,9 +154,14 @@ int kh_bank_destroy(kh_bank *b) {
   if (b->stream) hipStreamSynchronize(b->stream);
   if (b->front) hipStreamSynchronize(b->front);
   drop_graphs(b);
-  void *ptrs[] = {b->d_raw,   b->d_time[0], b->d_time[1], b->d_spec[0], b->d_spec[1], b->d_tmp, b->d_chans, b->d_resp,
+  for (int k = 0; k < kh_bank::MAX_SLOTS; k++) {
+    if (b->d_spec[k]) hipFree(b->d_spec[k]);
+    if (b->d_energy[k]) hipFree(b->d_energy[k]);
+    if (b->d_n0acc[k]) hipFree(b->d_n0acc[k]);
+  }
+  void *ptrs[] = {b->d_raw,   b->d_time[0], b->d_time[1], b->d_tmp, b->d_chans, b->d_resp,
                   b->d_ddesc, b->d_dstate,  b->d_idesc,   b->d_bb,     b->d_audio,  b->d_pcm,    b->d_status,
-                  b->d_istatus, b->d_energy[0], b->d_energy[1], b->d_n0acc[0], b->d_n0acc[1], b->d_n0state, b->d_scalar,
+                  b->d_istatus, b->d_n0state, b->d_scalar,
                   b->d_lists,
                   b->d_fmstat, b->d_fmwork, b->d_fmcarry, b->d_decaypow, b->d_rtp, b->d_rtpstate};
   for (void *p : ptrs)
@@ -244,8 +252,8 @@ kh_bank *kh_bank_create(const struct kh_bank_config *cfg) {
   A(&b->d_raw, P * b->raw_stride, true);
   A(&b->d_time[0], P * b->time_stride * sizeof(float2), true);
   A(&b->d_time[1], P * b->time_stride * sizeof(float2), true);
-  A(&b->d_spec[0], P * b->spec_stride * sizeof(float2), false);
-  A(&b->d_spec[1], P * b->spec_stride * sizeof(float2), false);
+  if (const char *e = getenv("KA9Q_HIP_SLOTS")) b->nslots = std::min(std::max(atoi(e), 2), (int)kh_bank::MAX_SLOTS);
+  for (int k = 0; k < b->nslots; k++) A(&b->d_spec[k], P * b->spec_stride * sizeof(float2), false);
   if (N > KH_MAX_SMALL_N) A(&b->d_tmp, P * b->spec_stride * sizeof(float2), false);
   A(&b->d_chans, C * sizeof(ChanDesc), true);
   A(&b->d_resp, C * ND * sizeof(float2), true);
@@ -257,7 +265,7 @@ kh_bank *kh_bank_create(const struct kh_bank_config *cfg) {
   A(&b->d_pcm, C * b->pcm_stride * sizeof(int16_t), true);
   A(&b->d_status, C * T * sizeof(kh_status), true);
   A(&b->d_istatus, P * T * sizeof(kh_input_status), true);
-  for (int k = 0; k < 2; k++) {
+  for (int k = 0; k < b->nslots; k++) {
     A(&b->d_energy[k], P * T * std::max(ingest_chunks(cfg->L), fused_ingest_tiles(N)) * sizeof(float), true);
     A(&b->d_n0acc[k], n0_part_floats() * P * T * sizeof(float), true);
   }
@@ -615,6 +623,7 @@ int kh_bank_execute(kh_bank *b, unsigned int nblocks) {
   for (int i = 0; i < P; i++) {
     HostOsc &lo = b->lo2[i], &dp = b->doppler[i];
     id[i].gain_factor = b->gain[i];
+    id[i].pad = 0;
     id[i].lo2 = NcoArgs{lo.phase, lo.freq_now, lo.rate, !(lo.freq_now == 0 && lo.rate == 0 && lo.phase == 0), 0};
     id[i].doppler = NcoArgs{dp.phase, dp.freq_now, dp.rate, dp.freq_set != 0, 0}; // radio.c:180
     lo.advance(need);
@@ -624,10 +633,18 @@ int kh_bank_execute(kh_bank *b, unsigned int nblocks) {
   for (int i = 0; i < P; i++)
     if (id[i].lo2.active || id[i].doppler.active) b->fused_now = false;
   if (sf != b->front && !KH_HIP(hipStreamSynchronize(b->front))) return -1; // an earlier pipelined front half
-  // the back half that last read slot sp (two launches ago) must be done before the front half overwrites it
+  // the back half that last read slot sp (nslots launches ago) must be done before the front half overwrites it.  With
+  // two slots that back half ends about when this front half is dispatched, and a wait that really blocks across
+  // hardware queues costs ~10 us; with three it has long finished
   if (sf != sb && !KH_HIP(hipStreamWaitEvent(sf, b->ev_back_done[sp], 0))) return -1;
-  if (!KH_HIP(hipMemcpyAsync(b->d_idesc, id, P * sizeof(IngestDesc), hipMemcpyHostToDevice, sf))) return -1;
-  if (!KH_HIP(hipEventRecord(b->idesc_ev[slot], sf))) return -1;
+  // (a copy-engine operation between two kernels of a stream costs a hand-over in each direction: the descriptors
+  // are uploaded only when they differ from what the device already holds, i.e. while an oscillator runs or after a
+  // gain change)
+  if (b->idesc_dev.size() != (size_t)P || memcmp(b->idesc_dev.data(), id, P * sizeof(IngestDesc)) != 0) {
+    if (!KH_HIP(hipMemcpyAsync(b->d_idesc, id, P * sizeof(IngestDesc), hipMemcpyHostToDevice, sf))) return -1;
+    if (!KH_HIP(hipEventRecord(b->idesc_ev[slot], sf))) return -1;
+    b->idesc_dev.assign(id, id + P);
+  }
 
   int rc = 0;
   if (prof) {
@@ -665,7 +682,7 @@ int kh_bank_execute(kh_bank *b, unsigned int nblocks) {
   if (b->n_fm) b->fm_parity ^= 1;
   b->cur ^= 1;
   b->last_sp = sp;
-  b->sp ^= 1;
+  b->sp = (sp + 1) % b->nslots;
   // consume the raw ring
   for (int i = 0; i < P; i++) {
     size_t const rest = b->fill[i] - need;
