@@ -67,6 +67,7 @@ struct kh_bank {
   hipEvent_t ev_front_done[MAX_SLOTS] = {}, ev_back_done[MAX_SLOTS] = {};
   int sp = 0, last_sp = 0, pipeline = 1;
   std::vector<IngestDesc> idesc_dev; // what d_idesc holds
+  bool slot_used[MAX_SLOTS] = {};    // ev_back_done[slot] has been recorded
   int nslots = 3; // ring depth of what the front half hands to the back half (KA9Q_HIP_SLOTS, 2..4)
   int fused_ingest = 1;   // policy (KA9Q_HIP_FUSED_INGEST)
   int ride_n0 = 1;        // policy (KA9Q_HIP_RIDE_N0)
@@ -235,8 +236,9 @@ kh_bank *kh_bank_create(const struct kh_bank_config *cfg) {
     ok = ok && KH_HIP(hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking));
     ok = ok && KH_HIP(hipStreamCreateWithFlags(&b->front, hipStreamNonBlocking));
   }
-  for (auto &e : b->ev_front_done) ok = ok && KH_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-  for (auto &e : b->ev_back_done) ok = ok && KH_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+  unsigned const evflags = hipEventDisableTiming;
+  for (auto &e : b->ev_front_done) ok = ok && KH_HIP(hipEventCreateWithFlags(&e, evflags));
+  for (auto &e : b->ev_back_done) ok = ok && KH_HIP(hipEventCreateWithFlags(&e, evflags));
   ok = ok && KH_HIP(hipHostMalloc((void **)&b->h_idesc, kh_bank::IDESC_SLOTS * P * sizeof(IngestDesc), hipHostMallocDefault));
   for (auto &e : b->idesc_ev) ok = ok && KH_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
   b->raw_stride = (payload_bytes(cfg->payload, T * L) + 15) & ~(size_t)15;
@@ -636,7 +638,12 @@ int kh_bank_execute(kh_bank *b, unsigned int nblocks) {
   // the back half that last read slot sp (nslots launches ago) must be done before the front half overwrites it.  With
   // two slots that back half ends about when this front half is dispatched, and a wait that really blocks across
   // hardware queues costs ~10 us; with three it has long finished
-  if (sf != sb && !KH_HIP(hipStreamWaitEvent(sf, b->ev_back_done[sp], 0))) return -1;
+  // (asked on the host first: a wait that is already satisfied would still put a barrier packet into the front queue,
+  // and the command processor spends microseconds on each)
+  if (sf != sb && b->slot_used[sp] && hipEventQuery(b->ev_back_done[sp]) != hipSuccess &&
+      !KH_HIP(hipStreamWaitEvent(sf, b->ev_back_done[sp], 0)))
+    return -1;
+  (void)hipGetLastError(); // hipEventQuery's hipErrorNotReady is not an error
   // (a copy-engine operation between two kernels of a stream costs a hand-over in each direction: the descriptors
   // are uploaded only when they differ from what the device already holds, i.e. while an oscillator runs or after a
   // gain change)
@@ -678,7 +685,10 @@ int kh_bank_execute(kh_bank *b, unsigned int nblocks) {
     if (!rc && g->seen >= 0) g->seen++;
   }
   if (rc) return rc;
-  if (sf != sb && !KH_HIP(hipEventRecord(b->ev_back_done[sp], sb))) return -1;
+  if (sf != sb) {
+    if (!KH_HIP(hipEventRecord(b->ev_back_done[sp], sb))) return -1;
+    b->slot_used[sp] = true;
+  }
   if (b->n_fm) b->fm_parity ^= 1;
   b->cur ^= 1;
   b->last_sp = sp;
