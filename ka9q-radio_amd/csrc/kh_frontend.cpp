@@ -71,8 +71,9 @@ int correct(int funcube, struct kh_fe_state *state, void *raw, size_t in_bytes, 
   hipStream_t st = default_stream();
   size_t const total = (size_t)samples * nblocks;
   DevBuf in(raw, in_bytes, true, st);
-  DevBuf oi(funcube ? raw : (void *)out_i, funcube ? 0 : total * sizeof(float), false, st);
-  DevBuf oq(funcube ? raw : (void *)out_q, funcube ? 0 : total * sizeof(float), false, st);
+  // hackrf: the two float rails; funcube corrects in place (these two then just alias the input view)
+  DevBuf oi(funcube ? in.d : (void *)out_i, funcube ? 0 : total * sizeof(float), false, st);
+  DevBuf oq(funcube ? in.d : (void *)out_q, funcube ? 0 : total * sizeof(float), false, st);
   std::lock_guard<std::mutex> lock(g_scratch_mutex);
   size_t const part_bytes = up256((size_t)nblocks * fe_chunks((int)samples) * 6 * sizeof(long long));
   size_t const par_bytes = up256(nblocks * sizeof(FeParams));
