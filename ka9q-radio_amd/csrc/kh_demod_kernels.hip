@@ -863,9 +863,9 @@ __global__ __launch_bounds__(64) void kh_demod_linear(float2 *__restrict__ baseb
           v = cmulc(v, ph); // s *= conjf(pll.vco.phasor)
           float phase;
           if (d.square)
-            phase = atan2f(2 * v.x * v.y, v.x * v.x - v.y * v.y); // cargf(s*s)
+            phase = fast_atan2f(2 * v.x * v.y, v.x * v.x - v.y * v.y); // cargf(s*s)
           else
-            phase = atan2f(v.y, v.x);
+            phase = fast_atan2f(v.y, v.x); // cargf: kh_fm.cuh, 2.5e-7; the loop filter sees it through gains of ~1e-3
           // run_pll, osc.c:91-107
           float feedback = d.pll_integrator_gain * s.pll_integrator + d.pll_prop_gain * phase;
           s.pll_integrator += phase;
