@@ -55,6 +55,15 @@ int main(void) {
   P(kh_channel_config, shift);
   printf("kh_status %zu\n", sizeof(struct kh_status));
   printf("kh_input_status %zu\n", sizeof(struct kh_input_status));
+  printf("kh_rtp_chunk %zu\n", sizeof(struct kh_rtp_chunk));
+  printf("kh_rtp_state %zu\n", sizeof(struct kh_rtp_state));
+  printf("kh_ax25_frame %zu\n", sizeof(struct kh_ax25_frame));
+  P(kh_ax25_frame, data);
+  printf("kh_afsk_bit %zu\n", sizeof(struct kh_afsk_bit));
+  printf("kh_afsk_status %zu\n", sizeof(struct kh_afsk_status));
+  printf("kh_pl_result %zu\n", sizeof(struct kh_pl_result));
+  printf("kh_dtmf_result %zu\n", sizeof(struct kh_dtmf_result));
+  printf("kh_fe_state %zu\n", sizeof(struct kh_fe_state));
   printf("enum %d %d %d %d\n", NONE, COMPLEX, CROSS_CONJ, REAL);
   return 0;
 }
@@ -79,6 +88,12 @@ int main(void) {
     assert int(out["kh_channel_config.shift"]) == pyka9q.ChannelConfig.shift.offset
     assert int(out["kh_status"]) == C.sizeof(pyka9q.Status) == pyka9q.STATUS_DTYPE.itemsize
     assert int(out["kh_input_status"]) == pyka9q.INPUT_STATUS_DTYPE.itemsize
+    assert int(out["kh_rtp_chunk"]) == pyka9q.Bank.RTP_CHUNK.itemsize and int(out["kh_rtp_state"]) == pyka9q.Bank.RTP_STATE.itemsize
+    assert int(out["kh_ax25_frame"]) == pyka9q.Afsk.FRAME.itemsize == 1040
+    assert int(out["kh_ax25_frame.data"]) == pyka9q.Afsk.FRAME.fields["data"][1]
+    assert int(out["kh_afsk_bit"]) == pyka9q.Afsk.BIT.itemsize and int(out["kh_afsk_status"]) == pyka9q.Afsk.STATUS.itemsize
+    assert int(out["kh_pl_result"]) == pyka9q.Tones.PL.itemsize and int(out["kh_dtmf_result"]) == pyka9q.Tones.DTMF.itemsize
+    assert int(out["kh_fe_state"]) == pyka9q.FE_STATE.itemsize
 
 
 def _no_gpu():
@@ -108,6 +123,14 @@ def test_no_device_means_loud_failure_not_a_cpu_path():
     assert L.execute_filter_input(None) == -1 and L.execute_filter_output(None, 0) == -1
     assert L.delete_filter_input(None) == 0 and L.delete_filter_output(None) == 0
     assert L.kh_bank_destroy(None) == 0 and L.kh_bank_execute(None, 1) == -1
+    # the packet / tone / front-end entry points fail the same way
+    assert not L.kh_afsk_create(1, 1, 1, 0) and not L.kh_tones_create(1, 1)
+    assert L.kh_afsk_destroy(None) == 0 and L.kh_tones_destroy(None) == 0
+    st = pyka9q.fe_state(1.0)
+    iq = np.zeros(8, np.int8)
+    oi, oq = np.full(4, 7.0, np.float32), np.full(4, 7.0, np.float32)
+    assert L.kh_hackrf_correct(st.ctypes.data, iq.ctypes.data, 4, 1, 1, 1e-7, oi.ctypes.data, oq.ctypes.data) == -1
+    assert (oi == 7.0).all() and (oq == 7.0).all()
 
 
 def test_product_does_not_touch_the_oracle():
