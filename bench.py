@@ -242,7 +242,7 @@ def main():
         dom = max((k for k in stages if k != "carry" and k not in empty), key=lambda k: stages[k]["ms"])
         traffic = None  # HBM bytes per launch of that kernel from the committed PMC passes (profiles/, tools/summarize_prof.py)
         try:
-            prof = json.load(open(os.path.join(ROOT, "profiles", "r01_step6_hbm_traffic.json")))["kernels"]
+            prof = json.load(open(os.path.join(ROOT, "profiles", "r01_step7_hbm_traffic.json")))["kernels"]
             key = {"fft1": "kh_fft_cols", "fft2": "kh_fft_rows", "chan": "kh_back_a", "demod": "kh_fm_finish_w", "n0": "kh_n0_pass1"}.get(dom)
             hit = [v for k, v in prof.items() if key and key in k]
             if hit and world == 1 and T == 32:
@@ -276,7 +276,7 @@ def main():
             "stages": stages,
             "roofline": {"bound": "hbm", "kernel": kernel_name, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS,
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic,
-                         "traffic_source": "profiles/r01_step6_hbm_traffic.json (separate rocprofv3 --pmc passes of this command)" if traffic else None,
+                         "traffic_source": "profiles/r01_step7_hbm_traffic.json (separate rocprofv3 --pmc passes of this command)" if traffic else None,
                          "algorithmic_bytes_per_launch": sb[dom], "avg_launch_ms": dom_ms},
         }
         if probe is not None:

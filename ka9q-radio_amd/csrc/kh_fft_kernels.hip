@@ -278,7 +278,7 @@ constexpr int TILE_W = 16;
 template <int RA, int RB, int NT, bool INGEST>
 __global__ __launch_bounds__(NT, 4) void kh_fft_cols(const float2 *__restrict__ time, size_t in_stride,
                                                   float2 *__restrict__ tmp, size_t spec_in_stride, int N2, int L,
-                                                  const float2 *__restrict__ tw, BigTwiddle bt, ColsIngest ing) {
+                                                  const float2 *__restrict__ tw, ColsTwiddle ct, ColsIngest ing) {
   constexpr int W = TILE_W, R = RA * RB;
   constexpr int I1 = W * RB / NT; // RA-point transforms per lane
   constexpr int I2 = W * RA / NT; // RB-point transforms per lane
@@ -375,20 +375,36 @@ __global__ __launch_bounds__(NT, 4) void kh_fft_cols(const float2 *__restrict__ 
 #pragma unroll
     for (int bb = 0; bb < RB; bb++) z[bb] = make_float2(zr[u][bb], zi[u][bb]);
     reg_fft<RB, -1>(z);
-    // four-step twiddle W_N^{n2 k1}, k1 = c + RA*(8q + j):  W_N^{n2 (c + 8 RA q)} W_N^{n2 RA j}  (every index < N)
-    // (scheduling fences: the compiler otherwise hoists all of the table reads above the transform and spills)
+    // four-step twiddle W_N^{n2 k1}, k1 = c + RA*(8q + j):  W_N^{n2 (c + 8 RA q)} W_N^{n2 RA j}, both factors from tables
+    // laid out for this kernel (16-byte loads; the generic coarse x fine product cost 22 8-byte loads and 11 products
+    // per lane, 6 us of the pass at N = 2^18).  Issuing the reads ahead of the transform, or three waves per SIMD
+    // without the spills, measured the same.
+    // (scheduling fences: the compiler otherwise hoists all of the table reads above the transform and spills more)
     __builtin_amdgcn_sched_barrier(0);
-    unsigned const n2 = (unsigned)(tile * W + w);
-    float2 uj[8];
+    int const n2 = tile * W + w;
+    float2 uj[8], tq[RB / 8];
+    {
+      const float4 *up = reinterpret_cast<const float4 *>(ct.uj) + (size_t)n2 * 4;
 #pragma unroll
-    for (int j = 1; j < 8; j++) uj[j] = big_tw(bt, n2 * (unsigned)(RA * j));
+      for (int j = 0; j < 4; j++) {
+        float4 const t = up[j];
+        uj[2 * j] = make_float2(t.x, t.y);
+        uj[2 * j + 1] = make_float2(t.z, t.w);
+      }
+      const float4 *tp = reinterpret_cast<const float4 *>(ct.tq) + ((size_t)n2 * RA + c) * (RB / 16);
+#pragma unroll
+      for (int q = 0; q < RB / 16; q++) {
+        float4 const t = tp[q];
+        tq[2 * q] = make_float2(t.x, t.y);
+        tq[2 * q + 1] = make_float2(t.z, t.w);
+      }
+    }
 #pragma unroll
     for (int q = 0; q < RB / 8; q++) {
-      float2 const tq = big_tw(bt, n2 * (unsigned)(c + RA * 8 * q));
 #pragma unroll
       for (int j = 0; j < 8; j++) {
         int const d = 8 * q + j;
-        float2 const wf = j ? cmul(tq, uj[j]) : tq;
+        float2 const wf = j ? cmul(tq[q], uj[j]) : tq[q];
         buf_store2(cmul(z[d], wf), rout, (c * N2 + w) * 8, RA * d * row_bytes);
       }
       __builtin_amdgcn_sched_barrier(0);
@@ -492,17 +508,18 @@ template <int RA, int RB, int NT>
 static int launch_cols(hipStream_t st, const float2 *time, size_t in_stride, float2 *tmp, size_t spec_in_stride, int N2,
                        int L, int nblocks, int ninputs, const FftIngest *fi) {
   const float2 *tw = twiddle_table(RA * RB);
-  BigTwiddle bt = big_twiddle(RA * RB * N2);
-  if (!tw || !bt.fine) return -1;
+  static_assert(RB % 16 == 0, "tq rows are read as float4");
+  ColsTwiddle const ct = cols_twiddle(N2, RA, RB);
+  if (!tw || !ct.uj || !ct.tq) return -1;
   dim3 const grid(N2 / TILE_W, nblocks, ninputs);
   if (fi) {
     ColsIngest const ing{static_cast<const unsigned char *>(fi->raw), fi->raw_stride_bytes, fi->raw_bytes, fi->payload,
                          fi->hist_in, fi->hist_out, fi->hist_stride, fi->desc, fi->energy_part, fi->M - 1};
     hipLaunchKernelGGL((kh_fft_cols<RA, RB, NT, true>), grid, dim3(NT), 0, st, time, in_stride, tmp, spec_in_stride, N2, L,
-                       tw, bt, ing);
+                       tw, ct, ing);
   } else {
     hipLaunchKernelGGL((kh_fft_cols<RA, RB, NT, false>), grid, dim3(NT), 0, st, time, in_stride, tmp, spec_in_stride, N2,
-                       L, tw, bt, ColsIngest{});
+                       L, tw, ct, ColsIngest{});
   }
   return KH_HIP(hipGetLastError()) ? 0 : -1;
 }

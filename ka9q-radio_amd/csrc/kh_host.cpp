@@ -8,6 +8,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <array>
 #include <map>
 #include <mutex>
 #include <vector>
@@ -114,6 +115,29 @@ BigTwiddle big_twiddle(int n) {
   bt.fine = upload_table(hf);
   if (bt.coarse && bt.fine) g_bigtw[n] = bt;
   return bt;
+}
+
+static std::map<std::array<int, 3>, ColsTwiddle> g_colstw;
+ColsTwiddle cols_twiddle(int N2, int RA, int RB) {
+  std::lock_guard<std::mutex> lk(g_mutex);
+  std::array<int, 3> const key{N2, RA, RB};
+  auto it = g_colstw.find(key);
+  if (it != g_colstw.end()) return it->second;
+  double const n = (double)N2 * RA * RB;
+  int const nq = RB / 8;
+  auto w = [n](long idx) {
+    double const a = -2.0 * M_PI * (double)idx / n;
+    return make_float2((float)cos(a), (float)sin(a));
+  };
+  std::vector<float2> hu((size_t)N2 * 8), ht((size_t)N2 * RA * nq);
+  for (long n2 = 0; n2 < N2; n2++) {
+    for (int j = 0; j < 8; j++) hu[n2 * 8 + j] = w(n2 * RA * j);
+    for (int c = 0; c < RA; c++)
+      for (int q = 0; q < nq; q++) ht[(n2 * RA + c) * nq + q] = w(n2 * (c + RA * 8 * q));
+  }
+  ColsTwiddle ct{upload_table(hu), upload_table(ht)};
+  if (ct.uj && ct.tq) g_colstw[key] = ct;
+  return ct;
 }
 
 static bool is_pow2(unsigned v) { return v && !(v & (v - 1)); }

@@ -27,6 +27,12 @@ struct BigTwiddle {
   const float2 *fine;   // exp(-2 pi i k / N), k < 1024
 };
 BigTwiddle big_twiddle(int n);
+// The column pass's four-step twiddles W_N^{n2 k1}, k1 = c + RA*(8q + j), split as W^{n2 (c + 8 RA q)} W^{n2 RA j} and laid
+// out so that a lane reads its 8 + RB/8 factors with 16-byte loads: uj[n2][8], tq[n2][RA][RB/8]
+struct ColsTwiddle {
+  const float2 *uj, *tq;
+};
+ColsTwiddle cols_twiddle(int N2, int RA, int RB);
 
 // ---------------------------------------------------------------- transforms of any 2,3,5,7-smooth size (kh_anyfft.cuh)
 struct AnyPlan {
