@@ -276,7 +276,7 @@ __device__ __forceinline__ void ingest_tile(float2 (&v)[CNT], ColsIngest const &
 constexpr int TILE_W = 16;
 
 template <int RA, int RB, int NT, bool INGEST>
-__global__ __launch_bounds__(NT, 4) void kh_fft_cols(const float2 *__restrict__ time, size_t in_stride,
+__global__ __launch_bounds__(NT, NT == 512 ? 2 : 4) void kh_fft_cols(const float2 *__restrict__ time, size_t in_stride,
                                                   float2 *__restrict__ tmp, size_t spec_in_stride, int N2, int L,
                                                   const float2 *__restrict__ tw, ColsTwiddle ct, ColsIngest ing) {
   constexpr int W = TILE_W, R = RA * RB;
