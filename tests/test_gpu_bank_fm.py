@@ -44,7 +44,8 @@ def _run_pair(hip, L, M, D, fs, chans, x, nblocks_per_call, calls, flat=0, n0=Fa
             for c in range(C):
                 y, audio, sig = outs[c]
                 sl = slice(b * olen, (b + 1) * olen)
-                assert rel_rms(g_bb[c][sl], y) < 1e-5, f"baseband ch {c} block {b} call {call}"
+                err = rel_rms(g_bb[c][sl], y)
+                assert err < 1e-5, f"baseband ch {c} block {b} call {call}: {err:.2e}"
                 pcm_o = orc_scaleclip(audio)
                 d = np.abs(g_pcm[c][sl].astype(np.int32) - pcm_o.astype(np.int32))
                 assert d.max() <= 1, f"pcm ch {c} block {b} call {call}: max diff {d.max()}"
