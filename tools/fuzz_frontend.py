@@ -1,0 +1,120 @@
+#!/usr/bin/env python3
+"""Randomised parity sweep of the front-end corrections and the payload packer (kh_hackrf_correct, kh_funcube_correct,
+kh_hackrf_pack) against the oracle's restatement of hackrf.c:822-919, funcube.c:364-428 and hackrf.c:511-573 (test
+infrastructure, run on a GPU box): tools/fuzz_frontend.py [cases] [seed].  Random transfer sizes, block counts, split of the
+blocks into calls, DC offsets, gain imbalance, phase error, amplitude up to clipping, rotation direction, estimator rate.
+Bars as in tests/test_gpu_frontend.py."""
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, "oracle"), os.path.join(ROOT, "ka9q-radio_amd"), os.path.join(ROOT, "tests")):
+    sys.path.insert(0, p)
+import orc  # noqa: E402
+import pyka9q as hip  # noqa: E402
+
+
+def rel_rms(a, b):
+    n = np.linalg.norm(b)
+    return float(np.linalg.norm(a - b) / n) if n > 0 else float(np.linalg.norm(a - b))
+
+
+def check_state(got, ref, what):
+    for k, v in ref.items():
+        g = got[k][0]
+        if k in ("rotate_phase", "clips"):
+            assert int(g) == v, f"{what}: {k} {g} vs {v}"
+        else:
+            assert abs(float(g) - v) <= 1e-4 * abs(v) + 1e-7, f"{what}: {k} {g} vs {v}"
+
+
+def tone_iq(rng, n, full_scale):
+    t = np.arange(n)
+    amp = float(rng.uniform(0.05, 1.1)) * full_scale  # (beyond 1: clipping)
+    f = float(rng.uniform(-0.4, 0.4))
+    ph = 2 * np.pi * f * t + float(rng.uniform(0, 3)) * np.sin(2 * np.pi * float(rng.uniform(1e-5, 1e-3)) * t)
+    nz = float(rng.uniform(0.01, 0.2)) * full_scale
+    i = amp * np.cos(ph) + nz * rng.standard_normal(n) + float(rng.uniform(-0.1, 0.1)) * full_scale
+    q = float(rng.uniform(0.7, 1.3)) * amp * np.sin(ph + float(rng.uniform(-0.2, 0.2))) + nz * rng.standard_normal(n) + float(rng.uniform(-0.1, 0.1)) * full_scale
+    iq = np.empty(2 * n)
+    iq[0::2], iq[1::2] = i, q
+    return iq
+
+
+def hackrf_case(rng):
+    samples = int(rng.choice([5, 64, 1000, 4099, 16384, 65536, 131072]))
+    nblocks = int(rng.integers(1, 9 if samples <= 16384 else 4))
+    offset = int(rng.choice([-1, 0, 1, 3]))
+    imb0 = float(rng.choice([0.0, 1.0]))
+    rate = float(10 ** rng.uniform(-8, -5.5))
+    iq = np.clip(np.round(tone_iq(rng, samples * nblocks, 127.0)), -128, 127).astype(np.int8)
+    st_o, st_g = orc.fe_new(imb0), hip.fe_state(imb0)
+    oi, oq = orc.hackrf_rx(st_o, iq, samples, nblocks, offset, rate)
+    gi, gq, done = [], [], 0
+    while done < nblocks:
+        k = int(rng.integers(1, nblocks - done + 1))
+        a, b = hip.hackrf_correct(st_g, iq[2 * samples * done:2 * samples * (done + k)], samples, k, offset, rate)
+        gi.append(a)
+        gq.append(b)
+        done += k
+    gi, gq = np.concatenate(gi), np.concatenate(gq)
+    what = f"hackrf samples={samples} blocks={nblocks} offset={offset} imb0={imb0} rate={rate:.1e}"
+    bar = 1e-5 if samples <= 16384 else 5e-5
+    e = max(rel_rms(gi, oi), rel_rms(gq, oq))
+    assert e < bar, f"{what}: rails {e:.2e}"
+    check_state(st_g, orc.fe_fields(st_o), what)
+    return what, e
+
+
+def funcube_case(rng):
+    blocksize = int(rng.choice([16, 240, 1000, 4800]))
+    nblocks = int(rng.integers(1, 40))
+    rate = blocksize / (192000.0 * float(rng.uniform(0.2, 5.0)))
+    buf = np.clip(np.round(tone_iq(rng, blocksize * nblocks, 20000.0)), -32768, 32767).astype(np.int16)
+    st_o, st_g = orc.fe_new(1.0), hip.fe_state(1.0)
+    ref = orc.funcube_blocks(st_o, buf, blocksize, nblocks, rate)
+    got = hip.funcube_correct(st_g, buf, blocksize, nblocks, rate)
+    d = np.abs(got.byteswap().astype(np.int32) - ref.byteswap().astype(np.int32))
+    what = f"funcube blocksize={blocksize} blocks={nblocks} rate={rate:.1e}"
+    assert d.max() <= 1 and (d > 0).mean() < 2e-3, f"{what}: int16 output differs by {d.max()}, {(d > 0).mean():.1e} of the words"
+    check_state(st_g, orc.fe_fields(st_o), what)
+    return what, float((d > 0).mean())
+
+
+def pack_case(rng):
+    pt = int(rng.choice([97, 95, 98]))
+    n = int(rng.integers(1, 20000))
+    ip, qp = rng.uniform(-1, 1, n).astype(np.float32), rng.uniform(-1, 1, n).astype(np.float32)
+    atten = (127.0 if pt == 98 else 32767.0) * float(rng.uniform(0.01, 1.5))
+    ref, e_ref = orc.hackrf_pack(pt, ip, qp, atten)
+    got, e_got = hip.hackrf_pack(pt, ip, qp, atten)
+    what = f"pack pt={pt} n={n} atten={atten:.1f}"
+    assert np.array_equal(got, ref), f"{what}: payload bytes differ"
+    assert abs(e_got - e_ref) <= 1e-4 * e_ref, f"{what}: energy {e_got} vs {e_ref}"
+    return what, abs(e_got - e_ref) / e_ref
+
+
+def main():
+    cases = int(sys.argv[1]) if len(sys.argv) > 1 else 60
+    seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+    rng = np.random.default_rng(seed)
+    assert hip.lib().ka9q_hip_init(0) == 0, hip.last_error()
+    bad = 0
+    t0 = time.time()
+    for k in range(cases):
+        fn = [hackrf_case, funcube_case, pack_case][k % 3]
+        try:
+            what, e = fn(rng)
+            print(f"[{k}] ok  {e:.2e} {what}", flush=True)
+        except AssertionError as e:
+            bad += 1
+            print(f"[{k}] BAD {str(e)[:400]}", flush=True)
+    print(f"{cases} cases, {bad} bad, {time.time() - t0:.0f} s")
+    return 1 if bad else 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())
