@@ -8,6 +8,9 @@ The raw I/Q of the step is resident in HBM before the timed region; nothing cros
 
     python bench.py [--gpus N] [--steps K] [--warmup W]
 
+Before the W warm-up steps a fixed 0.25 s of untimed steps lets the GPU leave its idle clocks (KA9Q_BENCH_PREWARM_S
+overrides it; the counter passes of tools/profile_set.sh set 0); the K timed steps and the barriers are as the contract says.
+
 N > 1 is launched by torch.distributed.run, one rank per GPU: channels shard disjointly, every GPU recomputes
 the forward FFT of the same stream (SURVEY.md 8(e) option A); there is no data-path collective.
 """
