@@ -56,7 +56,7 @@ def main():
     seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
     rng = np.random.default_rng(seed)
     assert hip.lib().ka9q_hip_init(0) == 0, hip.last_error()
-    bad = explained = near_thr = quiet = 0
+    bad = explained = near_thr = quiet = cancel = 0
     t0 = time.time()
     for k in range(cases):
         logn = int(rng.integers(12, 19))
@@ -114,6 +114,12 @@ def main():
                 # fm_snr just above its threshold (fm.c:190-205): the fixed-point iteration contracts with a ratio close to
                 # 1 there, so the last bit of r = avg^2/var moves a result of ~0.1 by 1e-4
                 g, o = float(e.args[0][3]), float(e.args[0][4])
+                if o > 1e4 and abs(g - o) < 1e-3 * o:
+                    # a carrier 60 dB over the noise: fm.c:53-70 takes the variance as E[a^2] - E[a]^2, which cancels
+                    # to its last digits there, and snr = f(avg^2/var) carries that
+                    cancel += 1
+                    print(f"[{k}] snr {tag}: gpu {g:.1f} oracle {o:.1f} (variance cancellation at snr > 1e4)", flush=True)
+                    continue
                 if o < 0.5 and abs(g - o) < 5e-4:
                     near_thr += 1
                     print(f"[{k}] snr {tag}: gpu {g:.6f} oracle {o:.6f} (noise-only block at fm_snr's threshold)", flush=True)
@@ -122,7 +128,7 @@ def main():
             print(f"[{k}] BAD {tag}: {str(e)[:200]}", flush=True)
             print(tb, flush=True)
     print(f"{cases} cases, {bad} bad; explained: {explained} n0 (the reference's fp32 running sums against float64), "
-          f"{near_thr} snr at fm_snr's threshold, {quiet} noise-only channels under strong carriers; {time.time() - t0:.0f} s")
+          f"{near_thr} snr at fm_snr's threshold, {quiet} noise-only channels under strong carriers, {cancel} snr above 1e4; {time.time() - t0:.0f} s")
     return 1 if bad else 0
 
 
