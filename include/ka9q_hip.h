@@ -183,7 +183,9 @@ kh_bank *kh_bank_create(const struct kh_bank_config *cfg);
 int kh_bank_destroy(kh_bank *);
 int kh_bank_set_channel(kh_bank *, unsigned int ch, const struct kh_channel_config *);
 /* set_second_LO / set_doppler semantics (radio.c:233-240,342-352): f in cycles/sample, rate in
- * cycles/sample^2, phase kept (osc.c:24-27).  The caller applies radio.c:238's negation. */
+ * cycles/sample^2, phase kept (osc.c:24-27).  lo2_freq is exactly what radio.c:350 hands to set_osc
+ * (second_LO/samprate, NOT negated: tune.second_LO already carries set_freq's sign, radio.c:267,289);
+ * doppler_freq / doppler_rate are what radio.c:238 hands to set_osc, i.e. the caller negates both. */
 int kh_bank_set_lo(kh_bank *, unsigned int input, double lo2_freq, double doppler_freq, double doppler_rate);
 /* the two halves of kh_bank_set_lo on their own: set_second_LO touches only the LO2 oscillator (radio.c:350),
  * set_doppler only the Doppler one and restarts its sweep from doppler_freq (radio.c:238, osc.c:28-35) */

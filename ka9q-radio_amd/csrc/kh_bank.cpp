@@ -212,6 +212,17 @@ kh_bank *kh_bank_create(const struct kh_bank_config *cfg) {
   case KH_PT_CF32: case KH_PT_IQ12: case KH_PT_IQ16LE: case KH_PT_IQ8: case KH_PT_PCM16BE: break;
   default: set_error("kh_bank_create: unknown payload type %d", cfg->payload); return nullptr;
   }
+  // the fused column pass addresses the raw ring with 32-bit byte offsets (buffer descriptors): a ring of 2 GiB or
+  // more would wrap them silently
+  if (N > KH_MAX_SMALL_N && payload_bytes(cfg->payload, (size_t)cfg->max_blocks * cfg->L) >= ((size_t)1 << 31)) {
+    set_error("kh_bank_create: max_blocks*L = %zu samples of this payload exceed the 2 GiB raw ring the kernels can address",
+              (size_t)cfg->max_blocks * cfg->L);
+    return nullptr;
+  }
+  if (cfg->max_blocks > (unsigned)N0_MAXB) { // kh_n0_final keeps one launch's per-block means in LDS
+    set_error("kh_bank_create: max_blocks %u above %d", cfg->max_blocks, N0_MAXB);
+    return nullptr;
+  }
   kh_bank *b = new kh_bank();
   b->cfg = *cfg;
   b->N = N;
@@ -433,6 +444,10 @@ int kh_bank_set_gain(kh_bank *b, unsigned int input, float gain_factor) {
   return 0;
 }
 
+// the stream the front half (ingest, ring compaction) is issued on outside profiling passes: raw-ring writes go
+// there too, so that they are ordered behind a launch that still reads the ring (KA9Q_HIP_PIPELINE=0: one stream)
+static hipStream_t raw_stream(kh_bank *b) { return b->pipeline ? b->front : b->stream; }
+
 int kh_bank_write_input(kh_bank *b, unsigned int input, const void *payload, size_t count) {
   if (!b || input >= (unsigned)b->P || (!payload && count)) return -1;
   size_t const cap = (size_t)b->T * b->cfg.L;
@@ -441,10 +456,11 @@ int kh_bank_write_input(kh_bank *b, unsigned int input, const void *payload, siz
     return -1;
   }
   unsigned char *dst = b->d_raw + input * b->raw_stride + payload_bytes(b->cfg.payload, b->fill[input]);
-  // on the front stream: behind the ingest of any launch still reading the ring
-  if (!KH_HIP(hipMemcpyAsync(dst, payload, payload_bytes(b->cfg.payload, count), hipMemcpyDefault, b->front)))
+  // on the stream the front half runs on: behind the ingest of any launch still reading the ring
+  hipStream_t const ws = raw_stream(b);
+  if (!KH_HIP(hipMemcpyAsync(dst, payload, payload_bytes(b->cfg.payload, count), hipMemcpyDefault, ws)))
     return -1;
-  if (!KH_HIP(hipStreamSynchronize(b->front))) return -1; // the caller may reuse its buffer
+  if (!KH_HIP(hipStreamSynchronize(ws))) return -1; // the caller may reuse its buffer
   b->fill[input] += count;
   return 0;
 }
@@ -456,7 +472,7 @@ int kh_bank_write_zeros(kh_bank *b, unsigned int input, size_t count) {
     return -1;
   }
   unsigned char *dst = b->d_raw + input * b->raw_stride + payload_bytes(b->cfg.payload, b->fill[input]);
-  if (!KH_HIP(hipMemsetAsync(dst, 0, payload_bytes(b->cfg.payload, count), b->front))) return -1;
+  if (!KH_HIP(hipMemsetAsync(dst, 0, payload_bytes(b->cfg.payload, count), raw_stream(b)))) return -1;
   b->fill[input] += count;
   return 0;
 }
@@ -697,14 +713,16 @@ int kh_bank_execute(kh_bank *b, unsigned int nblocks) {
   for (int i = 0; i < P; i++) {
     size_t const rest = b->fill[i] - need;
     if (rest) {
+      // Move what is left to the head of the ring, ordered behind the ingest on its stream.  The move is by `need`
+      // samples, so pieces of at most `need` samples never overlap their own destination; with more than one launch
+      // queued (a latency-mode caller that writes T*L samples and consumes them with execute(1)) the pieces go in
+      // ascending order on the one stream, each landing where the piece before it has already been read.
       unsigned char *base = b->d_raw + i * b->raw_stride;
-      if (rest <= need) { // source and destination do not overlap; ordered behind the ingest on its stream
-        if (!KH_HIP(hipMemcpyAsync(base, base + payload_bytes(b->cfg.payload, need), payload_bytes(b->cfg.payload, rest),
-                                   hipMemcpyDeviceToDevice, sf)))
+      for (size_t off = 0; off < rest; off += need) {
+        size_t const n = std::min(need, rest - off);
+        if (!KH_HIP(hipMemcpyAsync(base + payload_bytes(b->cfg.payload, off), base + payload_bytes(b->cfg.payload, off + need),
+                                   payload_bytes(b->cfg.payload, n), hipMemcpyDeviceToDevice, sf)))
           return -1;
-      } else {
-        set_error("kh_bank_execute: more than one launch of samples queued; consume them first");
-        return -1;
       }
     }
     b->fill[i] = rest;

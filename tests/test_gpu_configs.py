@@ -295,8 +295,10 @@ def test_config5_full_256_pipelines_independent(hip):
     big.close()
 
 
-def test_back_to_back_launches_match_synchronised_ones(hip):
-    """kh_bank_execute is asynchronous and the two halves of consecutive launches overlap on two streams (double-buffered
+@pytest.mark.parametrize("pipeline_env", ["1", "0"])
+def test_back_to_back_launches_match_synchronised_ones(hip, monkeypatch, pipeline_env):
+    """(pipeline_env "0": KA9Q_HIP_PIPELINE=0, both halves and the raw-ring writes on the bank's one stream.)
+    kh_bank_execute is asynchronous and the two halves of consecutive launches overlap on two streams (double-buffered
     spectrum, IF-power and n0 partials; FM state by launch parity).  Six launches queued without a host sync in between
     must leave bit for bit the PCM, status and input status of six launches each followed by kh_bank_sync -- there are
     no atomics anywhere, so any difference is a hazard between launches."""
@@ -305,6 +307,7 @@ def test_back_to_back_launches_match_synchronised_ones(hip):
     calls = 6
     sigs = [(k - 4, 0.02 + 0.01 * k, 300.0 + 50 * k, 2500.0) for k in range(C)]
     x = np.ascontiguousarray(synth.wideband_fm(3, T * calls * L, fs, N, sigs), np.complex64)
+    monkeypatch.setenv("KA9Q_HIP_PIPELINE", pipeline_env)  # read by kh_bank_create
     banks = []
     for _ in range(2):
         b = hip.Bank(L, M, D, 1, C, T, fs, compute_n0=1, n0_low=-5500.0, n0_high=5500.0)
@@ -337,3 +340,40 @@ def test_back_to_back_launches_match_synchronised_ones(hip):
     a.close()
     q.close()
     src.close()
+
+
+def test_full_ring_consumed_one_block_at_a_time(hip):
+    """A latency-mode caller: T*L samples written at once, then consumed with execute(1) T times (the ring is compacted
+    after every launch while more than one launch of samples is still queued).  Every block must match the same
+    samples run as one execute(T): PCM +-1 LSB, status 1e-4 -- and nothing may be processed twice."""
+    fs, L, M, D, C, T = 1_000_000, 8192, 8193, 32, 3, 6
+    N = L + M - 1
+    sigs = [(-2, 0.05, 400.0, 2500.0), (0, 0.02, 700.0, 2000.0), (3, 0.1, 1000.0, 3000.0)]
+    x = np.ascontiguousarray(synth.wideband_fm(5, T * L, fs, N, sigs), np.complex64)
+    banks = []
+    for _ in range(2):
+        b = hip.Bank(L, M, D, 1, C, T, fs, compute_n0=1, n0_low=-5500.0, n0_high=5500.0)
+        for c, (k, *_r) in enumerate(sigs):
+            b.set_channel(c, demod=hip.KH_DEMOD_FM, rotate=synth.rotate_for(k, 12500.0, N, fs), low=-5500.0, high=5500.0,
+                          kaiser_beta=3.0)
+        banks.append(b)
+    whole, single = banks
+    olen = L // D
+    whole.write_input(0, x)
+    whole.execute(T)
+    single.write_input(0, x)
+    for blk in range(T):
+        single.execute(1)
+        for c in range(C):
+            sl = slice(blk * olen, (blk + 1) * olen)
+            d = np.abs(single.pcm(c, 1).astype(np.int32) - whole.pcm(c, T)[sl].astype(np.int32))
+            assert d.max() <= 1, (blk, c, int(d.max()))
+            a, w = single.status(c, 1)[0], whole.status(c, T)[blk]
+            for key in ("bb_power", "snr"):
+                assert abs(a[key] - w[key]) <= 1e-4 * abs(w[key]) + 1e-4, (key, blk, c, a[key], w[key])
+            assert a["squelch_open"] == w["squelch_open"]
+    # the ring is empty now: one more launch must be refused, not run on stale samples
+    with pytest.raises(Exception):
+        single.execute(1)
+    whole.close()
+    single.close()
