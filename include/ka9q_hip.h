@@ -351,6 +351,18 @@ int kh_funcube_correct(struct kh_fe_state *state, int16_t *sampbuf, unsigned int
 int kh_hackrf_pack(int payload, const float *ip, const float *qp, unsigned int chunk, float filter_atten, void *out,
                    float *output_energy);
 
+/* NO COUNTERPART IN THE REFERENCE.  kh_hackrf_pack for callers that cannot allocate device memory: code under HIP
+ * graph capture, tight serving loops, harnesses that forbid hipMalloc.  Same kernels and same results as
+ * kh_hackrf_pack, but: ip, qp, out and output_energy (may be NULL) are DEVICE pointers; the work is queued on `stream`
+ * (a hipStream_t; NULL: the library's own stream) and NOT synchronised; the per-workgroup energy partial sums live in
+ * a static 16 KiB device array that every GPU the library runs on holds until the process ends.  No hipMalloc /
+ * hipFree / allocating routine is called, so ka9q_hip_init must have run before (this call cannot initialise lazily).
+ * chunk > KH_PACK_NOALLOC_MAX_CHUNK is refused (-1 and a message).  All calls on one GPU share the array: calls that
+ * overlap in time on one GPU (two streams, two threads) race on it -- serialise them. */
+#define KH_PACK_NOALLOC_MAX_CHUNK 1048576
+int kh_hackrf_pack_noalloc(int payload, const float *ip, const float *qp, unsigned int chunk, float filter_atten, void *out,
+                           float *output_energy, void *stream);
+
 void *kh_bank_stream(kh_bank *); /* hipStream_t */
 /* per-kernel timing with HIP events on the bank's stream.  Stages: */
 enum kh_stage { KH_STAGE_INGEST = 0, KH_STAGE_FFT1, KH_STAGE_FFT2, KH_STAGE_N0, KH_STAGE_CHAN, KH_STAGE_DEMOD,

@@ -251,4 +251,93 @@ int launch_fe_pack(hipStream_t st, int pt, const float *ip, const float *qp, int
   return KH_HIP(hipGetLastError()) ? 0 : -1;
 }
 
+// ---------------------------------------------------------------- kh_hackrf_pack_noalloc
+// kh_hackrf_pack for callers that cannot allocate (HIP graph capture, tight serving loops): the same pack kernel, its
+// per-workgroup energy partial sums in a static device array instead of the library's growing scratch allocation, and
+// the final sum (kh_hackrf_pack adds the partials on the host, in order) by one more kernel that adds them in the same
+// order.  Every GPU holds its own copy of the array at its own address: the host only ever uses the address
+// hipGetSymbolAddress returned for the device (g_pack_scratch[device]), never the array's name.
+constexpr int PACK_NOALLOC_GROUPS = KH_PACK_NOALLOC_MAX_CHUNK / FE_NT; // 4096 floats = 16 KiB per GPU
+static_assert(PACK_NOALLOC_GROUPS * FE_NT == KH_PACK_NOALLOC_MAX_CHUNK, "the maximum is a whole number of workgroups");
+static __device__ __align__(256) float scratch[PACK_NOALLOC_GROUPS];
+constexpr int PACK_MAX_DEVICES = 64;
+static float *g_pack_scratch[PACK_MAX_DEVICES] = {};
+
+// once per device, with that device current (called from the library's init)
+int pack_noalloc_setup(int device) {
+  if (device < 0 || device >= PACK_MAX_DEVICES) return 0; // such a device simply has no no-alloc entry point
+  float *ptr = nullptr;
+  if (!KH_HIP(hipGetSymbolAddress((void **)&ptr, HIP_SYMBOL(scratch)))) return -1;
+  g_pack_scratch[device] = ptr;
+  return 0;
+}
+
+// the partials of kh_fe_pack, added in ascending order by one lane as the host loop of kh_hackrf_pack adds them
+__global__ __launch_bounds__(FE_NT) void kh_fe_energy_sum(const float *__restrict__ part, int groups, float *__restrict__ out) {
+  __shared__ float sh[PACK_NOALLOC_GROUPS];
+  for (int k = threadIdx.x; k < groups; k += FE_NT) sh[k] = part[k];
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float t = 0.f;
+    for (int k = 0; k < groups; k++) t += sh[k];
+    *out = t;
+  }
+}
+
+static bool is_device_pointer(const void *p) {
+  hipPointerAttribute_t a;
+  if (hipPointerGetAttributes(&a, p) != hipSuccess) {
+    (void)hipGetLastError();
+    return false;
+  }
+  return a.type == hipMemoryTypeDevice;
+}
+
 } // namespace kh
+
+extern "C" int kh_hackrf_pack_noalloc(int payload, const float *ip, const float *qp, unsigned int chunk, float filter_atten,
+                                      void *out, float *output_energy, void *stream) {
+  using namespace kh;
+  if (!ip || !qp || !out) {
+    set_error("kh_hackrf_pack_noalloc: NULL argument");
+    return -1;
+  }
+  if (payload != KH_PT_IQ16LE && payload != KH_PT_IQ12 && payload != KH_PT_IQ8) {
+    set_error("kh_hackrf_pack_noalloc: payload type %d is not one of IQ_PT, IQ_PT12, IQ_PT8", payload);
+    return -1;
+  }
+  if (chunk > KH_PACK_NOALLOC_MAX_CHUNK) {
+    set_error("kh_hackrf_pack_noalloc: chunk %u above the maximum of %d samples (use kh_hackrf_pack)", chunk,
+              KH_PACK_NOALLOC_MAX_CHUNK);
+    return -1;
+  }
+  int const device = initialised_device();
+  if (device < 0) { // initialising creates a stream: not something this entry point may do
+    set_error("kh_hackrf_pack_noalloc: call ka9q_hip_init first (this entry point allocates nothing, so it cannot do it)");
+    return -1;
+  }
+  float *const part = device < PACK_MAX_DEVICES ? g_pack_scratch[device] : nullptr;
+  if (!part) {
+    set_error("kh_hackrf_pack_noalloc: no scratch address for device %d", device);
+    return -1;
+  }
+  if (!KH_HIP(hipSetDevice(device))) return -1;
+  // a host pointer handed to a kernel is a GPU memory fault, not an error code: refuse it here
+  if (!is_device_pointer(ip) || !is_device_pointer(qp) || !is_device_pointer(out) ||
+      (output_energy && !is_device_pointer(output_energy))) {
+    set_error("kh_hackrf_pack_noalloc: ip, qp, out and output_energy must be device pointers");
+    return -1;
+  }
+  hipStream_t const st = stream ? static_cast<hipStream_t>(stream) : default_stream();
+  if (chunk == 0) {
+    if (output_energy && !KH_HIP(hipMemsetAsync(output_energy, 0, sizeof(float), st))) return -1;
+    return 0;
+  }
+  int const groups = fe_pack_groups((int)chunk);
+  if (launch_fe_pack(st, payload, ip, qp, (int)chunk, filter_atten, out, part)) return -1;
+  if (output_energy) {
+    hipLaunchKernelGGL(kh_fe_energy_sum, dim3(1), dim3(FE_NT), 0, st, part, groups, output_energy);
+    if (!KH_HIP(hipGetLastError())) return -1;
+  }
+  return 0;
+}

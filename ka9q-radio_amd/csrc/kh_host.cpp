@@ -56,8 +56,13 @@ static int init_locked(int device) {
     return -1;
   }
   if (!KH_HIP(hipStreamCreateWithFlags(&g_stream, hipStreamNonBlocking))) return -1;
+  if (pack_noalloc_setup(device)) return -1; // device address of kh_hackrf_pack_noalloc's static scratch
   g_device = device;
   return 0;
+}
+int initialised_device() {
+  std::lock_guard<std::mutex> lk(g_mutex);
+  return g_device;
 }
 int ensure_init() {
   std::lock_guard<std::mutex> lk(g_mutex);

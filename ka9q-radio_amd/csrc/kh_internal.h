@@ -16,6 +16,7 @@ void set_error(const char *fmt, ...);
 bool check_hip(hipError_t e, const char *what);
 #define KH_HIP(call) ::kh::check_hip((call), #call)
 int ensure_init();
+int initialised_device(); // the device the library runs on, or -1 before ka9q_hip_init / the first lazy init
 hipStream_t default_stream();
 
 // ---------------------------------------------------------------- twiddle tables (device resident, cached per size)
@@ -263,5 +264,7 @@ int launch_frontend(hipStream_t st, int funcube, const void *raw, int samples, i
                     kh_fe_state *state, long long *part, FeParams *params, float *out_i, float *out_q, void *out_be);
 int launch_fe_pack(hipStream_t st, int pt, const float *ip, const float *qp, int chunk, float atten, void *out,
                    float *energy_part);
+// kh_hackrf_pack_noalloc: address of its static device scratch on `device` (current when called), once per device
+int pack_noalloc_setup(int device);
 
 } // namespace kh

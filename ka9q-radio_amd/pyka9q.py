@@ -34,7 +34,7 @@ EXPORTS = [
     "kh_afsk_read_baseband",
     "kh_tones_create", "kh_tones_destroy", "kh_tones_write_pcm", "kh_tones_pcm_device_ptr", "kh_tones_commit_pcm",
     "kh_tones_execute", "kh_tones_sync", "kh_tones_read_pl", "kh_tones_read_dtmf",
-    "kh_hackrf_correct", "kh_funcube_correct", "kh_hackrf_pack",
+    "kh_hackrf_correct", "kh_funcube_correct", "kh_hackrf_pack", "kh_hackrf_pack_noalloc",
 ]
 
 
