@@ -71,6 +71,8 @@ struct kh_bank {
   int nslots = 3; // ring depth of what the front half hands to the back half (KA9Q_HIP_SLOTS, 2..4)
   int fused_ingest = 1;   // policy (KA9Q_HIP_FUSED_INGEST)
   int ride_n0 = 1;        // policy (KA9Q_HIP_RIDE_N0)
+  int n0_direct_mode = -1; // policy (KA9Q_HIP_N0_DIRECT): 0 never, 1 whenever possible, -1 (default) by transform size
+  int n0_spin = 1000;      // KA9Q_HIP_N0_SPIN: polls before a row-pass workgroup gives up (0: every block is re-read)
   bool fused_now = false; // this launch: large transform and no oscillator active
   // device
   unsigned char *d_raw = nullptr;
@@ -315,6 +317,8 @@ kh_bank *kh_bank_create(const struct kh_bank_config *cfg) {
   if (const char *e = getenv("KA9Q_HIP_PIPELINE")) b->pipeline = atoi(e);
   if (const char *e = getenv("KA9Q_HIP_FUSED_INGEST")) b->fused_ingest = atoi(e);
   if (const char *e = getenv("KA9Q_HIP_RIDE_N0")) b->ride_n0 = atoi(e);
+  if (const char *e = getenv("KA9Q_HIP_N0_DIRECT")) b->n0_direct_mode = atoi(e);
+  if (const char *e = getenv("KA9Q_HIP_N0_SPIN")) b->n0_spin = std::min(std::max(atoi(e), 0), 100000);
   b->chans.assign(C, ChanDesc{0, 0, COMPLEX, 0});
   b->ddesc.assign(C, DemodDesc{});
   b->ccfg.assign(C, kh_channel_config{});
@@ -513,6 +517,7 @@ static int upload_channels(kh_bank *b) {
 // kh_bank_execute builds the hipGraphs of this shape.
 // FRONT: convert + mix (radio.c:136-191) and the forward transform (filter.c:212-238) into slot b->sp.
 static bool n0_in_fft(const kh_bank *b);
+static bool n0_direct(const kh_bank *b);
 static int enqueue_front(kh_bank *b, hipStream_t st, unsigned int nblocks, bool prof) {
   int const L = b->cfg.L, M = b->cfg.M, N = b->N, P = b->P, sp = b->sp;
   size_t const need = (size_t)nblocks * L;
@@ -533,11 +538,16 @@ static int enqueue_front(kh_bank *b, hipStream_t st, unsigned int nblocks, bool 
   // launch_forward_fft records the mid event (ev[2]) between the two passes itself
   N0Plan const plan = n0_plan(N, b->cfg.samprate, b->cfg.n0_low, b->cfg.n0_high);
   bool const n0_on = b->cfg.compute_n0 && plan.valid;
+  N0Fuse nf{n0_on ? b->d_n0acc[sp] : nullptr, plan.start, plan.bincount, nullptr};
+  size_t const PT = (size_t)P * nblocks; // (the regions of d_n0acc are laid out for this call's block count)
+  if (n0_on && (n0_in_fft(b) || n0_direct(b))) nf.part1 = b->d_n0acc[sp] + PT * N0_SLOTS;
+  if (n0_on && n0_direct(b)) {
+    nf.sync = reinterpret_cast<unsigned *>(b->d_n0acc[sp] + PT * (N0_SLOTS + 2 * N0_GX));
+    nf.direct = 1;
+    nf.spin = b->n0_spin;
+  }
   if (launch_forward_fft(st, time, b->time_stride, 0, b->d_spec[sp], b->d_tmp, b->spec_stride, N, L, nblocks, P,
-                         prof ? b->ev[2] : nullptr,
-                         N0Fuse{n0_on ? b->d_n0acc[sp] : nullptr, plan.start, plan.bincount,
-                                (n0_on && n0_in_fft(b)) ? b->d_n0acc[sp] + (size_t)P * nblocks * N0_SLOTS : nullptr},
-                         fused ? &fi : nullptr))
+                         prof ? b->ev[2] : nullptr, nf, fused ? &fi : nullptr))
     return -1;
   // overlap-save history for the next call (filter.c:230), into the other buffer
   if (!fused && !fused_carry && launch_carry(st, time + need, b->d_time[b->cur ^ 1], b->time_stride * sizeof(float2),
@@ -550,6 +560,17 @@ static bool n0_in_fft(const kh_bank *b) {
   static int const env = getenv("KA9Q_HIP_N0_IN_FFT") ? atoi(getenv("KA9Q_HIP_N0_IN_FFT")) : 1; // A/B switch
   return env && b->cfg.compute_n0 && b->N <= KH_MAX_SMALL_N;
 }
+// Four-step transforms: the row pass can take compute_n0's second iteration itself (N0Fuse, kh_internal.h), which
+// saves reading the spectrum a second time (8 N bytes per block) and costs ~5 us at the end of every row-pass launch
+// (the hand-over between the tiles of a block).  Measured (tools/shape_bench.py, us per step without / with):
+// N = 2^18, T = 32: 67.7 / 72.1 -- the re-read hides behind the latency-bound channel wavefronts there;
+// N = 2^19, T = 32: 183.5 / 172.2; N = 2^20, T = 16: 164.8 / 161.1.  Hence: from 2^19 on, unless KA9Q_HIP_N0_DIRECT says
+// 0 (never) or 1 (whenever possible).
+static bool n0_direct(const kh_bank *b) {
+  if (b->n0_direct_mode == 0 || !b->cfg.compute_n0 || b->N <= KH_MAX_SMALL_N) return false;
+  if (b->n0_direct_mode < 0 && b->N < (1 << 19)) return false;
+  return n0_plan(b->N, b->cfg.samprate, b->cfg.n0_low, b->cfg.n0_high).valid != 0;
+}
 // BACK: compute_n0 (radio.c:422-465), per channel filter output (filter.c:240-384), demodulators, scaleclip.
 static int enqueue_back(kh_bank *b, hipStream_t st, unsigned int nblocks, bool prof) {
   int const L = b->cfg.L, N = b->N, P = b->P, C = b->C, sp = b->sp;
@@ -561,10 +582,14 @@ static int enqueue_back(kh_bank *b, hipStream_t st, unsigned int nblocks, bool p
   N0Pass1Args z;
   // (transforms that fit one workgroup have taken the second iteration themselves, from LDS: enqueue_front)
   bool const in_fft = n0_in_fft(b);
+  // (four-step transforms in direct mode: the row pass has left the second iteration's partial sums as well, except for
+  // blocks whose flag it raised; the iteration below then only runs for those)
+  const unsigned *dsync = n0_direct(b) ? reinterpret_cast<const unsigned *>(b->d_n0acc[sp] + (size_t)P * nblocks * (N0_SLOTS + 2 * N0_GX))
+                                       : nullptr;
   bool const ride = !in_fft && b->ride_n0 && chan_wave_supported(b->ND, b->olen) &&
-                    n0_pass1_args(&z, n0spec, b->spec_stride, N, plan, b->d_n0acc[sp], nblocks, P);
+                    n0_pass1_args(&z, n0spec, b->spec_stride, N, plan, b->d_n0acc[sp], nblocks, P, dsync);
   if (!ride && launch_n0(st, n0spec, b->spec_stride, N, b->cfg.samprate, plan, b->d_energy[sp], echunks, L, b->d_n0state,
-                         b->d_n0acc[sp], b->d_istatus, nblocks, P, in_fft ? 1 : 0))
+                         b->d_n0acc[sp], b->d_istatus, nblocks, P, in_fft ? 1 : 0, nullptr, dsync))
     return -1;
   if (prof) hipEventRecord(b->ev[4], st);
   int taken = 0;
@@ -578,7 +603,7 @@ static int enqueue_back(kh_bank *b, hipStream_t st, unsigned int nblocks, bool p
   N0FinalArgs nf;
   bool const ride_final = ride && taken && b->n_fm > 0 && fm_finish_wave_usable(b->olen, nblocks);
   if (ride && launch_n0(st, n0spec, b->spec_stride, N, b->cfg.samprate, plan, b->d_energy[sp], echunks, L, b->d_n0state,
-                        b->d_n0acc[sp], b->d_istatus, nblocks, P, taken, ride_final ? &nf : nullptr))
+                        b->d_n0acc[sp], b->d_istatus, nblocks, P, taken, ride_final ? &nf : nullptr, dsync))
     return -1;
   if (prof) hipEventRecord(b->ev[5], st);
   if (launch_demod(st, b->d_bb, b->bb_stride, b->olen, nblocks, C, b->d_ddesc, b->d_dstate,

@@ -164,7 +164,8 @@ __global__ __launch_bounds__(N0_FT) void kh_n0_final(N0FinalArgs Z) {
   n0_final_body(Z, blockIdx.x, sv, se);
 }
 
-int n0_part_floats() { return N0_SLOTS + 2 * N0_GX; }
+// per (input, block): first-iteration partials | {sum, count} pairs of the second | direct mode's two words (N0Fuse)
+int n0_part_floats() { return N0_SLOTS + 2 * N0_GX + N0_SYNC_STRIDE; }
 
 N0Plan n0_plan(int N, int samprate, float low, float high) {
   N0Plan p{0, 0, 0};
@@ -187,14 +188,14 @@ N0Plan n0_plan(int N, int samprate, float low, float high) {
 // launch_chan_wave so that the iteration shares the channel kernel's launch, and then calls launch_n0 with
 // pass1_done = 1 for the rest.
 int n0_pass1_args(N0Pass1Args *z, const float2 *spec, size_t spec_in_stride, int N, N0Plan plan, float *part, int nblocks,
-                  int ninputs) {
+                  int ninputs, const unsigned *sync) {
   if (spec == nullptr || !plan.valid) return 0;
-  *z = N0Pass1Args{spec, spec_in_stride, N, plan.start, plan.bincount, part, nblocks, ninputs, n0_partials(N), N0_GX};
+  *z = N0Pass1Args{spec, spec_in_stride, N, plan.start, plan.bincount, part, nblocks, ninputs, n0_partials(N), N0_GX, sync};
   return 1;
 }
 int launch_n0(hipStream_t st, const float2 *spec, size_t spec_in_stride, int N, int samprate, N0Plan plan,
               const float *energy_part, int echunks, int L, float *n0_state, float *part, void *input_status, int nblocks,
-              int ninputs, int pass1_done, N0FinalArgs *final_out) {
+              int ninputs, int pass1_done, N0FinalArgs *final_out, const unsigned *sync) {
   if (nblocks <= 0 || ninputs <= 0) return 0;
   if (nblocks > N0_MAXB) {
     set_error("at most %d blocks per launch", N0_MAXB);
@@ -203,7 +204,7 @@ int launch_n0(hipStream_t st, const float2 *spec, size_t spec_in_stride, int N, 
   kh_input_status *status = static_cast<kh_input_status *>(input_status);
   int const have_n0 = spec != nullptr;
   N0Pass1Args z;
-  int const valid = n0_pass1_args(&z, spec, spec_in_stride, N, plan, part, nblocks, ninputs);
+  int const valid = n0_pass1_args(&z, spec, spec_in_stride, N, plan, part, nblocks, ninputs, sync);
   if (valid && !pass1_done)
     hipLaunchKernelGGL(kh_n0_pass1, dim3(N0_GX * nblocks * ninputs), dim3(256), 0, st, z);
   N0FinalArgs const F{part, energy_part, echunks, L, N, samprate, valid, have_n0, n0_state, status, nblocks, ninputs};

@@ -262,13 +262,17 @@ __device__ __forceinline__ void ingest_tile(float2 (&v)[CNT], ColsIngest const &
     voff += step;
   }
   // The window reaches back into the history only in the first block(s) of a launch: those lanes then replace their
-  // zeros by the history samples (masked loads straight into v[k]).
+  // zeros by the history samples.  Buffer loads again (one running offset; 64-bit addresses would keep a register pair
+  // per outstanding load alive): sample s < 0 is element M1 + s of the history, and s >= 0 falls beyond its M1
+  // elements, so the load returns zero and the select keeps the new sample.
   if (__builtin_amdgcn_ballot_w64(s_lane < 0) != 0) { // wave-uniform
-    const float2 *hist = ing.hist_in + (size_t)i * ing.hist_stride + ing.M1;
+    __amdgpu_buffer_rsrc_t const rh = make_rsrc(ing.hist_in + (size_t)i * ing.hist_stride, (unsigned)ing.M1 * 8u);
+    int hoff = (ing.M1 + s_lane) * 8;
 #pragma unroll
     for (int k = 0; k < CNT; k++) {
-      int const s = s_lane + k * rstep_elems;
-      if (s < 0) v[k] = hist[s];
+      float2 const h = buf_load2(rh, hoff, 0);
+      if (s_lane + k * rstep_elems < 0) v[k] = h;
+      hoff += rstep_elems * 8;
     }
   }
 }
@@ -276,9 +280,10 @@ __device__ __forceinline__ void ingest_tile(float2 (&v)[CNT], ColsIngest const &
 constexpr int TILE_W = 16;
 
 template <int RA, int RB, int NT, bool INGEST>
-__global__ __launch_bounds__(NT, NT == 512 ? 2 : 4) void kh_fft_cols(const float2 *__restrict__ time, size_t in_stride,
+__global__ __launch_bounds__(NT, 4) void kh_fft_cols(const float2 *__restrict__ time, size_t in_stride,
                                                   float2 *__restrict__ tmp, size_t spec_in_stride, int N2, int L,
-                                                  const float2 *__restrict__ tw, ColsTwiddle ct, ColsIngest ing) {
+                                                  const float2 *__restrict__ tw, ColsTwiddle ct, ColsIngest ing, int b0,
+                                                  int nblocks, unsigned *__restrict__ n0sync) {
   constexpr int W = TILE_W, R = RA * RB;
   constexpr int I1 = W * RB / NT; // RA-point transforms per lane
   constexpr int I2 = W * RA / NT; // RB-point transforms per lane
@@ -287,9 +292,15 @@ __global__ __launch_bounds__(NT, NT == 512 ? 2 : 4) void kh_fft_cols(const float
   __shared__ float ex[RA * CS];
   __shared__ float red[NT / 64];
   int const tid = threadIdx.x;
-  int const tile = blockIdx.x, b = blockIdx.y, i = blockIdx.z;
+  // this launch handles blocks b0 .. b0 + gridDim.y - 1 of the nblocks of the call (kh_bank_execute); its scratch slot
+  // in tmp is the block's index within the launch: the groups of a call reuse the same scratch
+  int const tile = blockIdx.x, bl = blockIdx.y, b = b0 + bl, i = blockIdx.z;
   unsigned const tile_bytes = (unsigned)R * (unsigned)N2 * 8u; // the block's N points (8 MiB at most)
   int const row_bytes = N2 * 8;
+  // compute_n0, direct mode (N0Fuse): the row pass of this block counts its tiles in and may raise a flag; both words
+  // start at zero (plain stores: the row pass is a later kernel on the same stream)
+  if (n0sync != nullptr && tile == 0 && tid == 0)
+    *reinterpret_cast<uint2 *>(n0sync + N0_SYNC_STRIDE * ((size_t)i * nblocks + b)) = make_uint2(0u, 0u);
   float2 v[I1][RA];
   if constexpr (!INGEST) {
     __amdgpu_buffer_rsrc_t const rin = make_rsrc(time + i * in_stride + (size_t)b * L + tile * W, tile_bytes);
@@ -317,8 +328,6 @@ __global__ __launch_bounds__(NT, NT == 512 ? 2 : 4) void kh_fft_cols(const float
     // IF power of the block's new samples (radio.c:188,197: n >= M-1) and the next launch's history (filter.c:230:
     // the last M-1 points of the launch = window elements n >= L of its last block)
     float e = 0.f;
-    bool const last = b == (int)gridDim.y - 1;
-    float2 *ho = ing.hist_out + (size_t)i * ing.hist_stride;
 #pragma unroll
     for (int u = 0; u < I1; u++)
 #pragma unroll
@@ -326,10 +335,22 @@ __global__ __launch_bounds__(NT, NT == 512 ? 2 : 4) void kh_fft_cols(const float
         int const n = n_lane + (u * (NT / W) + RB * a) * N2;
         float2 const x = v[u][a];
         if (n >= ing.M1) e += x.x * x.x + x.y * x.y;
-        if (last && n >= L) ho[n - L] = x;
       }
+    if (b == nblocks - 1) { // uniform: window elements n >= L of the call's last block are the next history
+      // element n - L of hist_out; n < L makes the offset negative, i.e. out of range: the buffer unit drops the store
+      __amdgpu_buffer_rsrc_t const rho = make_rsrc(ing.hist_out + (size_t)i * ing.hist_stride, (unsigned)ing.M1 * 8u);
+#pragma unroll
+      for (int u = 0; u < I1; u++) {
+        int hoff = (n_lane + u * (NT / W) * N2 - L) * 8;
+#pragma unroll
+        for (int a = 0; a < RA; a++) {
+          buf_store2(v[u][a], rho, hoff, 0);
+          hoff += RB * N2 * 8;
+        }
+      }
+    }
     e = block_sum<NT>(e, red);
-    if (tid == 0) ing.energy_part[((size_t)i * gridDim.y + b) * gridDim.x + tile] = e;
+    if (tid == 0) ing.energy_part[((size_t)i * nblocks + b) * gridDim.x + tile] = e;
   }
 #pragma unroll
   for (int u = 0; u < I1; u++) {
@@ -367,7 +388,7 @@ __global__ __launch_bounds__(NT, NT == 512 ? 2 : 4) void kh_fft_cols(const float
     for (int bb = 0; bb < RB; bb++) zi[u][bb] = ex[c * CS + bb * W + w];
   }
   size_t const N = (size_t)R * N2;
-  __amdgpu_buffer_rsrc_t const rout = make_rsrc(tmp + i * spec_in_stride + (size_t)b * N + tile * W, tile_bytes);
+  __amdgpu_buffer_rsrc_t const rout = make_rsrc(tmp + i * spec_in_stride + (size_t)bl * N + tile * W, tile_bytes);
 #pragma unroll
   for (int u = 0; u < I2; u++) {
     int const item = tid + u * NT, w = item % W, c = item / W;
@@ -412,10 +433,10 @@ __global__ __launch_bounds__(NT, NT == 512 ? 2 : 4) void kh_fft_cols(const float
   }
 }
 
-template <int RA, int RB, int NT>
+template <int RA, int RB, int NT, bool DIRECT>
 __global__ __launch_bounds__(NT, 4) void kh_fft_rows(const float2 *__restrict__ tmp, float2 *__restrict__ spec,
                                                   size_t spec_in_stride, int N1, const float2 *__restrict__ tw,
-                                                  N0Fuse n0) {
+                                                  N0Fuse n0, int b0, int nblocks) {
   constexpr int W = TILE_W, R = RA * RB;
   constexpr int I1 = W * RB / NT, I2 = W * RA / NT;
   static_assert(I1 * NT == W * RB && I2 * NT == W * RA, "tile must divide evenly over the workgroup");
@@ -423,10 +444,13 @@ __global__ __launch_bounds__(NT, 4) void kh_fft_rows(const float2 *__restrict__ 
   constexpr int CS = W * RP;  // pitch of c (an odd multiple of 16 floats)
   __shared__ float ex[RA * CS];
   __shared__ float red[NT / 64];
+  __shared__ float th_sh;
+  __shared__ int ok_sh, arrived_sh;
+  if (DIRECT && threadIdx.x == 0) arrived_sh = 0; // (behind the exchange's barriers when it is used)
   int const tid = threadIdx.x;
-  int const tile = blockIdx.x, b = blockIdx.y, i = blockIdx.z;
+  int const tile = blockIdx.x, bl = blockIdx.y, b = b0 + bl, i = blockIdx.z; // (b0, nblocks: as in kh_fft_cols)
   size_t const N = (size_t)R * N1;
-  const float2 *src = tmp + i * spec_in_stride + (size_t)b * N + (size_t)tile * W * R;
+  const float2 *src = tmp + i * spec_in_stride + (size_t)bl * N + (size_t)tile * W * R;
   float2 v[I1][RA];
 #pragma unroll
   for (int u = 0; u < I1; u++) { // lanes run along the row: RB consecutive points, then the next row
@@ -469,25 +493,104 @@ __global__ __launch_bounds__(NT, 4) void kh_fft_rows(const float2 *__restrict__ 
     for (int bb = 0; bb < RB; bb++) zi[u][bb] = ex[c * CS + w * RP + bb];
   }
   __amdgpu_buffer_rsrc_t const rout = make_rsrc(spec + i * spec_in_stride + (size_t)b * N + tile * W, (unsigned)N * 8u);
+  if constexpr (!DIRECT) {
+    float pw = 0.f;
+#pragma unroll
+    for (int u = 0; u < I2; u++) {
+      int const item = tid + u * NT, w = item % W, c = item / W;
+      float2 z[RB];
+#pragma unroll
+      for (int bb = 0; bb < RB; bb++) z[bb] = make_float2(zr[u][bb], zi[u][bb]);
+      reg_fft<RB, -1>(z);
+#pragma unroll
+      for (int d = 0; d < RB; d++) {
+        int const k2 = c + RA * d;
+        float2 const x = z[d];
+        buf_store2(x, rout, (c * N1 + w) * 8, RA * d * N1 * 8); // X[k1 + N1*k2], k1 = tile*W + w
+        if (n0.part != nullptr && n0_bin_counts(tile * W + w + N1 * k2, (int)N, n0)) pw += x.x * x.x + x.y * x.y;
+      }
+    }
+    if (n0.part != nullptr) { // uniform: radio.c:451-461, first iteration (every counted bin)
+      pw = block_sum<NT>(pw, red);
+      if (tid == 0) n0.part[((size_t)i * nblocks + b) * N0_SLOTS + tile] = pw;
+    }
+  } else {
+  // ---- compute_n0, direct mode (N0Fuse)
+  static_assert(I2 == 1, "direct mode keeps one row of outputs per lane");
+  int const w = tid % W, c = tid / W;
+  float2 z[RB];
+#pragma unroll
+  for (int bb = 0; bb < RB; bb++) z[bb] = make_float2(zr[0][bb], zi[0][bb]);
+  reg_fft<RB, -1>(z);
+  // The power of every counted output (radio.c:440-447) stays behind in registers, and the tile's first-iteration sum
+  // is published BEFORE the stores go out, so that it travels while they drain -- without a workgroup barrier in
+  // front of the stores: every wave leaves its sum in LDS and counts itself in there; the wave that comes last adds
+  // the sums in wave order and signals for the workgroup: agent-scope store of the sum, wait for it, agent-scope add
+  // (MI355X_MICROARCH.md: hand-off by one lane per storing workgroup, write-through stores and loads on both sides).
+  float pv[RB]; // -1 for the outputs that do not count
   float pw = 0.f;
 #pragma unroll
-  for (int u = 0; u < I2; u++) {
-    int const item = tid + u * NT, w = item % W, c = item / W;
-    float2 z[RB];
+  for (int d = 0; d < RB; d++) {
+    bool const counts = n0_bin_counts(tile * W + w + N1 * (c + RA * d), (int)N, n0);
+    float const p = z[d].x * z[d].x + z[d].y * z[d].y;
+    pv[d] = counts ? p : -1.f;
+    if (counts) pw += p;
+  }
 #pragma unroll
-    for (int bb = 0; bb < RB; bb++) z[bb] = make_float2(zr[u][bb], zi[u][bb]);
-    reg_fft<RB, -1>(z);
+  for (int o = 32; o > 0; o >>= 1) pw += __shfl_xor(pw, o, 64);
+  size_t const pt = (size_t)i * nblocks + b;
+  constexpr int NTILES_MAX = N0_SLOTS;
+  int const ntiles = gridDim.x; // row tiles of the block, <= 64
+  if ((tid & 63) == 0) {
+    red[tid >> 6] = pw;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); // the sum is in LDS before the count says so
+    if (__hip_atomic_fetch_add(&arrived_sh, 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_WORKGROUP) == NT / 64 - 1) {
+      float t = 0.f;
 #pragma unroll
-    for (int d = 0; d < RB; d++) {
-      int const k2 = c + RA * d;
-      float2 const x = z[d];
-      buf_store2(x, rout, (c * N1 + w) * 8, RA * d * N1 * 8); // X[k1 + N1*k2], k1 = tile*W + w
-      if (n0.part != nullptr && n0_bin_counts(tile * W + w + N1 * k2, (int)N, n0)) pw += x.x * x.x + x.y * x.y;
+      for (int wv = 0; wv < NT / 64; wv++) t += red[wv];
+      __hip_atomic_store(n0.part + pt * N0_SLOTS + tile, t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __hip_atomic_fetch_add(n0.sync + N0_SYNC_STRIDE * pt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
   }
-  if (n0.part != nullptr) { // uniform
-    pw = block_sum<NT>(pw, red);
-    if (tid == 0) n0.part[((size_t)i * gridDim.y + b) * N0_SLOTS + tile] = pw;
+#pragma unroll
+  for (int d = 0; d < RB; d++) buf_store2(z[d], rout, (c * N1 + w) * 8, RA * d * N1 * 8); // X[k1 + N1*k2], k2 = c + RA*d
+  __syncthreads(); // (red is read again below)
+  // The block's other tiles: dispatched next to this one, so their sums arrive within microseconds.  The wait is
+  // bounded all the same (a workgroup that is not resident cannot be waited for): when it runs out the block's flag
+  // goes up and a later kernel takes the second iteration from the stored spectrum.
+  if (tid == 0) {
+    unsigned seen = 0;
+    for (int it = 0; it < n0.spin; it++) { // x ~0.1 us
+      seen = __hip_atomic_load(n0.sync + N0_SYNC_STRIDE * pt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (seen >= (unsigned)ntiles) break;
+      __builtin_amdgcn_s_sleep(2);
+    }
+    ok_sh = seen >= (unsigned)ntiles;
+    if (!ok_sh) n0.sync[N0_SYNC_STRIDE * pt + 1] = 1u; // read by a later kernel
+  }
+  __syncthreads();
+  if (!ok_sh) return; // uniform
+  if (tid < 64) { // the wave whose lane polled: radio.c:456,461, twice the mean of the first iteration
+    float t = tid < ntiles ? __hip_atomic_load(n0.part + pt * N0_SLOTS + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.f;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) t += __shfl_xor(t, o, 64);
+    if (tid == 0) th_sh = (t / n0.bincount) * 2;
+  }
+  __syncthreads();
+  float const th = th_sh;
+  float s1 = 0.f, c1 = 0.f;
+#pragma unroll
+  for (int d = 0; d < RB; d++)
+    if (pv[d] >= 0.f && pv[d] < th) { // radio.c:457-460
+      s1 += pv[d];
+      c1 += 1.f;
+    }
+  s1 = block_sum<NT>(s1, red);
+  c1 = block_sum<NT>(c1, red);
+  float2 *pairs = reinterpret_cast<float2 *>(n0.part1 + pt * (2 * NTILES_MAX));
+  if (tid == 0) pairs[tile] = make_float2(s1, c1);
+  if (tile == 0 && tid >= ntiles && tid < NTILES_MAX) pairs[tid] = make_float2(0.f, 0.f); // kh_n0_final adds all 64
   }
 }
 
@@ -506,30 +609,34 @@ static int launch_small(hipStream_t st, const void *time, size_t in_stride, int 
 
 template <int RA, int RB, int NT>
 static int launch_cols(hipStream_t st, const float2 *time, size_t in_stride, float2 *tmp, size_t spec_in_stride, int N2,
-                       int L, int nblocks, int ninputs, const FftIngest *fi) {
+                       int L, int nblocks, int ninputs, const FftIngest *fi, int b0, int gblocks, unsigned *n0sync) {
   const float2 *tw = twiddle_table(RA * RB);
   static_assert(RB % 16 == 0, "tq rows are read as float4");
   ColsTwiddle const ct = cols_twiddle(N2, RA, RB);
   if (!tw || !ct.uj || !ct.tq) return -1;
-  dim3 const grid(N2 / TILE_W, nblocks, ninputs);
+  dim3 const grid(N2 / TILE_W, gblocks, ninputs);
   if (fi) {
     ColsIngest const ing{static_cast<const unsigned char *>(fi->raw), fi->raw_stride_bytes, fi->raw_bytes, fi->payload,
                          fi->hist_in, fi->hist_out, fi->hist_stride, fi->desc, fi->energy_part, fi->M - 1};
     hipLaunchKernelGGL((kh_fft_cols<RA, RB, NT, true>), grid, dim3(NT), 0, st, time, in_stride, tmp, spec_in_stride, N2, L,
-                       tw, ct, ing);
+                       tw, ct, ing, b0, nblocks, n0sync);
   } else {
     hipLaunchKernelGGL((kh_fft_cols<RA, RB, NT, false>), grid, dim3(NT), 0, st, time, in_stride, tmp, spec_in_stride, N2,
-                       L, tw, ct, ColsIngest{});
+                       L, tw, ct, ColsIngest{}, b0, nblocks, n0sync);
   }
   return KH_HIP(hipGetLastError()) ? 0 : -1;
 }
 template <int RA, int RB, int NT>
 static int launch_rows(hipStream_t st, const float2 *tmp, float2 *spec, size_t spec_in_stride, int N1, int nblocks,
-                       int ninputs, N0Fuse n0) {
+                       int ninputs, N0Fuse n0, int b0, int gblocks) {
   const float2 *tw = twiddle_table(RA * RB);
   if (!tw) return -1;
-  hipLaunchKernelGGL((kh_fft_rows<RA, RB, NT>), dim3(N1 / TILE_W, nblocks, ninputs), dim3(NT), 0, st, tmp, spec,
-                     spec_in_stride, N1, tw, n0);
+  if (n0.direct)
+    hipLaunchKernelGGL((kh_fft_rows<RA, RB, NT, true>), dim3(N1 / TILE_W, gblocks, ninputs), dim3(NT), 0, st, tmp, spec,
+                       spec_in_stride, N1, tw, n0, b0, nblocks);
+  else
+    hipLaunchKernelGGL((kh_fft_rows<RA, RB, NT, false>), dim3(N1 / TILE_W, gblocks, ninputs), dim3(NT), 0, st, tmp, spec,
+                       spec_in_stride, N1, tw, n0, b0, nblocks);
   return KH_HIP(hipGetLastError()) ? 0 : -1;
 }
 
@@ -551,6 +658,23 @@ int n0_partials(int N) { // first-pass partial sums the forward transform leaves
 int fused_ingest_tiles(int N) { // IF power partial sums the fused column pass leaves per (input, block); 0: no fused pass
   if (N <= KH_MAX_SMALL_N) return 0;
   return (N / four_step_n1(N)) / TILE_W; // one per column tile
+}
+
+// blocks per (column pass, row pass) pair of a four-step transform: KA9Q_HIP_FFT_GROUP_MB (default 64) MiB of scratch
+// per group, but never fewer blocks than fill the chip once (1024 workgroups of 256 threads, 512 of 512)
+int fft_group_blocks(int N, int nblocks, int ninputs) {
+  static int const mb = getenv("KA9Q_HIP_FFT_GROUP_MB") ? atoi(getenv("KA9Q_HIP_FFT_GROUP_MB")) : 64;
+  if (mb <= 0) return nblocks;
+  size_t const per_block = (size_t)N * 8 * (size_t)ninputs;
+  int g = (int)(((size_t)mb << 20) / per_block);
+  int const N1 = four_step_n1(N), N2 = N / N1;
+  auto slots = [](int n) { return n >= 1024 ? 512 : n >= 256 ? 1024 : 2048; }; // workgroups of that pass the chip holds
+  int const fill_cols = (slots(N1) + N2 / TILE_W * ninputs - 1) / (N2 / TILE_W * ninputs);
+  int const fill_rows = (slots(N2) + N1 / TILE_W * ninputs - 1) / (N1 / TILE_W * ninputs);
+  int const fill = fill_cols > fill_rows ? fill_cols : fill_rows;
+  if (g < fill) g = fill;
+  if (g < 1) g = 1;
+  return g < nblocks ? g : nblocks;
 }
 
 int launch_forward_fft(hipStream_t st, const void *time, size_t in_stride, int real_input, float2 *spec, float2 *tmp,
@@ -599,21 +723,30 @@ int launch_forward_fft(hipStream_t st, const void *time, size_t in_stride, int r
   int const N1 = four_step_n1(N), N2 = N / N1;
   (void)e;
   const float2 *t = static_cast<const float2 *>(time);
-  int rc = -1;
-  switch (N1) {
-  case 128: rc = launch_cols<8, 16, 128>(st, t, in_stride, tmp, spec_in_stride, N2, L, nblocks, ninputs, fi); break;
-  case 256: rc = launch_cols<16, 16, 256>(st, t, in_stride, tmp, spec_in_stride, N2, L, nblocks, ninputs, fi); break;
-  case 512: rc = launch_cols<16, 32, 256>(st, t, in_stride, tmp, spec_in_stride, N2, L, nblocks, ninputs, fi); break;
-  case 1024: rc = launch_cols<32, 32, 512>(st, t, in_stride, tmp, spec_in_stride, N2, L, nblocks, ninputs, fi); break;
-  }
-  if (rc) return rc;
-  if (mid_event) hipEventRecord(mid_event, st);
-  switch (N2) {
-  case 128: rc = launch_rows<8, 16, 128>(st, tmp, spec, spec_in_stride, N1, nblocks, ninputs, n0); break;
-  case 256: rc = launch_rows<16, 16, 256>(st, tmp, spec, spec_in_stride, N1, nblocks, ninputs, n0); break;
-  case 512: rc = launch_rows<16, 32, 256>(st, tmp, spec, spec_in_stride, N1, nblocks, ninputs, n0); break;
-  case 1024: rc = launch_rows<32, 32, 512>(st, tmp, spec, spec_in_stride, N1, nblocks, ninputs, n0); break;
-  default: rc = -1;
+  // Blocks per pair of launches.  The column pass writes the block's N points to scratch and the row pass reads them
+  // back: a group's scratch is sized to stay in the 256 MiB Infinity Cache between the two, and every group of a call
+  // reuses the same scratch, so most of that round trip never reaches HBM.
+  int const group = fft_group_blocks(N, nblocks, ninputs);
+  unsigned *const n0sync = n0.direct ? n0.sync : nullptr;
+  int rc = 0;
+  for (int b0 = 0; b0 < nblocks && !rc; b0 += group) {
+    int const gb = nblocks - b0 < group ? nblocks - b0 : group;
+    rc = -1;
+    switch (N1) {
+    case 128: rc = launch_cols<8, 16, 128>(st, t, in_stride, tmp, spec_in_stride, N2, L, nblocks, ninputs, fi, b0, gb, n0sync); break;
+    case 256: rc = launch_cols<16, 16, 256>(st, t, in_stride, tmp, spec_in_stride, N2, L, nblocks, ninputs, fi, b0, gb, n0sync); break;
+    case 512: rc = launch_cols<16, 32, 256>(st, t, in_stride, tmp, spec_in_stride, N2, L, nblocks, ninputs, fi, b0, gb, n0sync); break;
+    case 1024: rc = launch_cols<32, 32, 512>(st, t, in_stride, tmp, spec_in_stride, N2, L, nblocks, ninputs, fi, b0, gb, n0sync); break;
+    }
+    if (rc) return rc;
+    if (mid_event && b0 == 0) hipEventRecord(mid_event, st);
+    switch (N2) {
+    case 128: rc = launch_rows<8, 16, 128>(st, tmp, spec, spec_in_stride, N1, nblocks, ninputs, n0, b0, gb); break;
+    case 256: rc = launch_rows<16, 16, 256>(st, tmp, spec, spec_in_stride, N1, nblocks, ninputs, n0, b0, gb); break;
+    case 512: rc = launch_rows<16, 32, 256>(st, tmp, spec, spec_in_stride, N1, nblocks, ninputs, n0, b0, gb); break;
+    case 1024: rc = launch_rows<32, 32, 512>(st, tmp, spec, spec_in_stride, N1, nblocks, ninputs, n0, b0, gb); break;
+    default: rc = -1;
+    }
   }
   return rc;
 }

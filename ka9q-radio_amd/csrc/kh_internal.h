@@ -136,7 +136,18 @@ struct N0Fuse {
   // (radio.c:451-462: bins below twice the first mean) is taken there as well and the spectrum is never re-read.
   // part1 = part + ninputs*nblocks*N0_SLOTS (kh_n0.cuh's layout: 2*64 floats per (input, block)); nullptr: not wanted.
   float *part1 = nullptr;
+  // N > KH_MAX_SMALL_N, direct mode: the row pass takes the second iteration itself, from the registers that still
+  // hold its part of the spectrum, so the spectrum is not read a second time.  Its threshold is twice the mean of ALL
+  // row tiles' first-iteration sums of the block: every workgroup publishes its sum (part, agent-scope store) and
+  // counts itself in (sync[N0_SYNC_STRIDE pt]), then waits -- for a bounded time -- until the block's other tiles have done the
+  // same.  A workgroup whose wait runs out raises sync[N0_SYNC_STRIDE pt + 1]; the second iteration of that block is then taken by
+  // re-reading the spectrum (kh_n0_pass1 / kh_back_a), as without direct mode.  part1 receives the {sum, count} pair
+  // of every row tile (kh_n0_final's layout).  The column pass clears both words of its blocks.
+  unsigned *sync = nullptr;
+  int direct = 0;
+  int spin = 1000; // polls of ~0.1 us before a workgroup gives up (KA9Q_HIP_N0_SPIN; 0 sends every block to the re-read)
 };
+constexpr int N0_SYNC_STRIDE = 64; // 32-bit words per (input, block) in N0Fuse::sync: lines of its own
 int n0_partials(int N);
 // fi != nullptr (N > KH_MAX_SMALL_N only): the first pass reads the raw ring itself instead of `time` -- wire format
 // -> float x gain_factor (radio.c:136-178; no oscillator: the caller uses launch_ingest when one is active), leaves
@@ -187,13 +198,14 @@ struct N0Plan {
 };
 N0Plan n0_plan(int N, int samprate, float low, float high);
 // fills *z with the second iteration's arguments; 0 if there is nothing to do (compute_n0 off, empty bin range)
+// sync (may be null): direct mode's words (N0Fuse); the iteration then only runs for blocks whose flag is raised
 int n0_pass1_args(N0Pass1Args *z, const float2 *spec, size_t spec_in_stride, int N, N0Plan plan, float *part, int nblocks,
-                  int ninputs);
+                  int ninputs, const unsigned *sync = nullptr);
 // pass1_done: the second iteration has already run (inside launch_chan_wave's kernel)
 int launch_n0(hipStream_t st, const float2 *spec, size_t spec_in_stride, int N, int samprate, N0Plan plan,
               const float *energy_part, int echunks /*partial sums per (input, block)*/, int L, float *n0_state,
               float *part /*n0_part_floats() per (input,block)*/, void *input_status, int nblocks, int ninputs,
-              int pass1_done = 0, N0FinalArgs *final_out = nullptr);
+              int pass1_done = 0, N0FinalArgs *final_out = nullptr, const unsigned *sync = nullptr);
 // final_out != nullptr: kh_n0_final is not launched; *final_out receives its arguments for launch_demod
 // demodulators + scaleclip
 int launch_demod(hipStream_t st, float2 *baseband, size_t bb_stride, int olen, int nblocks, int nchan,

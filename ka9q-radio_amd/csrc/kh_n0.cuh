@@ -16,6 +16,7 @@ struct N0Pass1Args {
   int N, start, bincount; // radio.c:440-447: bins (start + n) mod N, n < bincount
   float *part;            // layout below
   int nblocks, ninputs, npart0, gx;
+  const unsigned *sync; // direct mode (N0Fuse): sync[N0_SYNC_STRIDE pt + 1] != 0 marks the blocks whose second iteration is still due
 };
 
 struct N0FinalArgs { // kh_n0_final: partial sums -> n0 per block, smoothing (radio.c:197-202), IF power
@@ -41,6 +42,7 @@ __device__ __forceinline__ void n0_pass1_body(N0Pass1Args const &Z, int wg, floa
   int const slice = wg % Z.gx, b = (wg / Z.gx) % Z.nblocks, i = wg / (Z.gx * Z.nblocks);
   const float2 *fd = Z.spec + (size_t)i * Z.spec_in_stride + (size_t)b * Z.N;
   size_t const pt = (size_t)i * Z.nblocks + b;
+  if (Z.sync != nullptr && Z.sync[N0_SYNC_STRIDE * pt + 1] == 0) return; // uniform: the row pass has taken this block's iteration
   const float *p0 = Z.part + pt * N0_SLOTS;
   float *p1 = Z.part + (size_t)Z.ninputs * Z.nblocks * N0_SLOTS + pt * (2 * N0_GX);
   // radio.c:456,461: twice the mean of iteration 0 (npart0 <= 64 partials, added in a fixed order)

@@ -377,3 +377,45 @@ def test_full_ring_consumed_one_block_at_a_time(hip):
         single.execute(1)
     whole.close()
     single.close()
+
+
+@pytest.mark.parametrize("shape", [(1_000_000, 8192, 8193, 32), (8_000_000, 131072, 131073, 256)])
+def test_compute_n0_modes_agree(hip, monkeypatch, shape):
+    """compute_n0's second iteration (radio.c:451-462) has three routes for a four-step transform: the spectrum is read a
+    second time (KA9Q_HIP_N0_DIRECT=0); the row pass takes it from its registers once the tiles of a block have exchanged
+    their first-iteration sums (=1); and, when a tile's bounded wait for the others runs out, the block falls back to the
+    re-read (forced here with KA9Q_HIP_N0_SPIN=0).  All three must give the float64 evaluation of the same definition
+    to 1e-4 and each other to 1e-5, block after block (the smoothing of radio.c:199-202 carries across launches)."""
+    fs, L, M, D = shape
+    N = L + M - 1
+    T, calls = 3, 2
+    sigs = [(-2, 0.05, 400.0, 2500.0), (0, 0.2, 700.0, 2000.0), (3, 0.1, 1000.0, 3000.0)]  # channel 0 sits in the n0 passband
+    x = np.ascontiguousarray(synth.wideband_fm(11, T * calls * L, fs, N, sigs), np.complex64)
+    results = {}
+    for name, env in (("reread", {"KA9Q_HIP_N0_DIRECT": "0"}), ("direct", {"KA9Q_HIP_N0_DIRECT": "1"}),
+                      ("fallback", {"KA9Q_HIP_N0_DIRECT": "1", "KA9Q_HIP_N0_SPIN": "0"})):
+        monkeypatch.delenv("KA9Q_HIP_N0_SPIN", raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)  # read by kh_bank_create
+        bank = hip.Bank(L, M, D, 1, 1, T, fs, compute_n0=1, n0_low=-5500.0, n0_high=5500.0)
+        bank.set_channel(0, demod=hip.KH_DEMOD_FM, rotate=0, low=-5500.0, high=5500.0, kaiser_beta=3.0)
+        n0s, specs = [], []
+        for call in range(calls):
+            bank.write_input(0, x[call * T * L:(call + 1) * T * L])
+            bank.execute(T)
+            n0s += [float(v) for v in bank.input_status(0, T)["n0"]]
+            specs += [bank.spectrum(0, b) for b in range(T)]
+        bank.close()
+        results[name] = n0s
+        if name == "reread":
+            ref, prev = [], None
+            for sp in specs:
+                v = _n0_float64(sp, N, -5500.0, 5500.0, fs)
+                prev = v if prev is None else prev + .005 * (v - prev)
+                ref.append(prev)
+    for name, n0s in results.items():
+        for b, (g, r) in enumerate(zip(n0s, ref)):
+            assert abs(g - r) <= 1e-4 * r, (name, b, g, r)
+    for name in ("direct", "fallback"):
+        for b, (g, r) in enumerate(zip(results[name], results["reread"])):
+            assert abs(g - r) <= 1e-5 * abs(r), (name, b, g, r)

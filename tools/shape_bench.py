@@ -16,7 +16,7 @@ x = torch.randn(P, T * L, 2, device="cuda", generator=g) * 0.05
 t = torch.arange(T * L, device="cuda", dtype=torch.float64)
 x[:, :, 0] += 0.3 * torch.cos(2 * np.pi * 0.001 * t).float()   # a carrier near DC so that FM squelches open
 x[:, :, 1] += 0.3 * torch.sin(2 * np.pi * 0.001 * t).float()
-bank = pyka9q.Bank(L, M, D, P, C, T, FS, payload=pyka9q.KH_PT_CF32, compute_n0=1, n0_low=-5500.0, n0_high=5500.0)
+bank = pyka9q.Bank(L, M, D, P, C, T, FS, payload=pyka9q.KH_PT_CF32, compute_n0=int(os.environ.get("SB_N0", "1")), n0_low=-5500.0, n0_high=5500.0)
 bank.keep_audio(0)
 if demod == "fm":
     bank.keep_baseband(0)
