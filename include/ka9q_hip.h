@@ -17,14 +17,17 @@
 
 #include <stddef.h>
 #include <stdint.h>
+#include <stdlib.h>
 #include <pthread.h>
 
 #ifdef __cplusplus
 typedef struct kh_cf32 { float re, im; } kh_cf32;   /* layout of C's `complex float` */
+typedef struct kh_cf64 { double re, im; } kh_cf64;  /* layout of C's `complex double` */
 extern "C" {
 #else
 #include <complex.h>
 typedef float _Complex kh_cf32;
+typedef double _Complex kh_cf64;
 #endif
 
 /* ------------------------------------------------------------------ library */
@@ -105,8 +108,32 @@ int window_rfilter(int L, int M, kh_cf32 *response, float beta);      /* filter.
 int set_filter(struct filter_out *, float low, float high, float kaiser_beta); /* filter.c:660 */
 float noise_gain(struct filter_out const *);                          /* filter.c:631 */
 
-/* The reference's create_filter_input_file (filter.c:96, experimental mmap'd spectrum, no live
- * caller: main.c:334 is commented out) and notch (filter.c:707-727, no caller) are not provided. */
+/* filter.c:96-160 (experimental, no live caller: main.c:334 is commented out): as create_filter_input, but
+ * fdomain[] is a shared mapping of `file` (created/truncated, N or N/2+1 bins), so that other processes can
+ * read every block's spectrum; master->fd holds the descriptor.  delete_filter_input unmaps and closes it
+ * (the reference leaks both). */
+struct filter_in *create_filter_input_file(unsigned int L, unsigned int M, enum filtertype in_type, char *file);
+
+/* filter.h:97-108, filter.c:707-727: experimental one-pole complex notch (no caller anywhere in the reference).
+ * The state is in the caller-visible struct, as there. */
+struct notchfilter {
+  kh_cf64 osc_phase; /* phase of the local complex mixer */
+  kh_cf64 osc_step;  /* mixer phase increment (frequency) */
+  kh_cf32 dcstate;   /* average signal at the mixer frequency */
+  float bw;          /* relative bandwidth of the notch */
+};
+struct notchfilter *notch_create(double f, float bw); /* filter.c:707; f in cycles/sample */
+#define notch_delete(x) free(x)                       /* filter.h:107 */
+/* filter.c:719, one sample per call as the reference declares it (NaN for a NULL filter).  Each call is a
+ * host-to-device round trip: use kh_notch_block for a stream. */
+kh_cf32 notch(struct notchfilter *, kh_cf32 s);
+/* the same recurrence over n samples in place (buf: host or device memory); 0 or -1.  Not in the reference. */
+int kh_notch_block(struct notchfilter *, kh_cf32 *buf, int n);
+
+/* osc.h:32-39 (set_osc, step_osc, renorm_osc, is_phasor_init, init_pll, run_pll) is NOT exported: those are
+ * per-sample host calls on caller-owned structs, and a receiver built on this library keeps the reference's
+ * osc.o for them.  Inside the library the same oscillators run in closed form on the
+ * device (kh_bank_set_lo / kh_bank_set_doppler, the PLL of kh_bank's linear demodulator). */
 
 /* ------------------------------------------------------------------ decimate.h */
 struct hb15_state { /* decimate.h:4-9 */

@@ -1128,4 +1128,36 @@ int launch_carry(hipStream_t st, const void *src, void *dst, size_t row_stride_b
   return KH_HIP(hipGetLastError()) ? 0 : -1;
 }
 
+// ================================================================ notch: filter.c:719-727
+// One-pole notch at the mixer frequency: spin down, subtract and track the DC term, spin back up.  The recurrence runs
+// through every sample (dcstate and the fp64 phasor), in the reference's order of operations and precisions: one lane.
+__global__ __launch_bounds__(64) void kh_notch(NotchState *__restrict__ st, float2 *__restrict__ buf, int n) {
+  if (threadIdx.x != 0) return;
+  double pr = st->pr, pi = st->pi;
+  double const sr = st->sr, si = st->si;
+  float dr = st->dr, di = st->di;
+  float const bw = st->bw;
+  for (int k = 0; k < n; k++) {
+    float2 const x = buf[k];
+    // s = s * conj(osc_phase) - dcstate, in double, rounded to float
+    float const ur = (float)(((double)x.x * pr + (double)x.y * pi) - (double)dr);
+    float const ui = (float)(((double)x.y * pr - (double)x.x * pi) - (double)di);
+    dr += bw * ur; // dcstate += bw * s
+    di += bw * ui;
+    buf[k] = make_float2((float)((double)ur * pr - (double)ui * pi), (float)((double)ur * pi + (double)ui * pr)); // s *= osc_phase
+    double const npr = pr * sr - pi * si; // osc_phase *= osc_step
+    pi = pr * si + pi * sr;
+    pr = npr;
+  }
+  st->pr = pr;
+  st->pi = pi;
+  st->dr = dr;
+  st->di = di;
+}
+int launch_notch(hipStream_t st, NotchState *state, float2 *buf, int n) {
+  if (n <= 0) return 0;
+  hipLaunchKernelGGL(kh_notch, dim3(1), dim3(64), 0, st, state, buf, n);
+  return KH_HIP(hipGetLastError()) ? 0 : -1;
+}
+
 } // namespace kh

@@ -8,6 +8,9 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <unistd.h>
 #include <array>
 #include <map>
 #include <mutex>
@@ -172,6 +175,7 @@ struct FilterInImpl {
   float2 *d_spec[2];  // spectrum of block k lives in d_spec[k & 1]
   float2 *d_tmp;
   hipStream_t stream;
+  size_t mapped_bytes; // create_filter_input_file: fdomain is a mapping of this size, not pinned memory
 };
 struct FilterOutImpl {
   int N, ND, olen;
@@ -239,7 +243,19 @@ void ka9q_hip_free(void *p) {
 }
 
 // ------------------------------------------------------------------ filter.c:57
+static struct filter_in *create_input_common(unsigned int L, unsigned int M, enum filtertype in_type, const char *file);
 struct filter_in *create_filter_input(unsigned int L, unsigned int M, enum filtertype in_type) {
+  return create_input_common(L, M, in_type, nullptr);
+}
+// ------------------------------------------------------------------ filter.c:96
+struct filter_in *create_filter_input_file(unsigned int L, unsigned int M, enum filtertype in_type, char *file) {
+  if (file == nullptr) {
+    set_error("create_filter_input_file: NULL file name");
+    return nullptr;
+  }
+  return create_input_common(L, M, in_type, file);
+}
+static struct filter_in *create_input_common(unsigned int L, unsigned int M, enum filtertype in_type, const char *file) {
   if (ensure_init()) return nullptr;
   unsigned const N = L + M - 1;
   if (L == 0 || M == 0 || !((is_pow2(N) && N >= 256 && N <= (1u << 20)) || make_any_plan((int)N).npass)) {
@@ -272,7 +288,23 @@ struct filter_in *create_filter_input(unsigned int L, unsigned int M, enum filte
   im->cur = 0;
   bool ok = KH_HIP(hipStreamCreateWithFlags(&im->stream, hipStreamNonBlocking));
   size_t const nbins = im->real ? N / 2 + 1 : N;
-  master->fdomain = (kh_cf32 *)ka9q_hip_alloc(nbins * sizeof(kh_cf32));
+  master->fd = -1;
+  im->mapped_bytes = 0;
+  if (file == nullptr) {
+    master->fdomain = (kh_cf32 *)ka9q_hip_alloc(nbins * sizeof(kh_cf32));
+  } else { // filter.c:111-124,133-146: the spectrum lives in a shared mapping of the file
+    master->fd = open(file, O_CREAT | O_TRUNC | O_RDWR, 0644);
+    void *map = MAP_FAILED;
+    if (master->fd >= 0 && ftruncate(master->fd, (off_t)(nbins * sizeof(kh_cf32))) == 0)
+      map = mmap(nullptr, nbins * sizeof(kh_cf32), PROT_READ | PROT_WRITE, MAP_SHARED, master->fd, 0);
+    if (map == MAP_FAILED) {
+      set_error("create_filter_input_file: cannot create and map %s", file);
+      ok = false;
+    } else {
+      master->fdomain = (kh_cf32 *)map;
+      im->mapped_bytes = nbins * sizeof(kh_cf32);
+    }
+  }
   void *ib = ka9q_hip_alloc(N * im->esize);
   ok = ok && master->fdomain && ib;
   if (ib) memset(ib, 0, N * im->esize); // "Clear earlier state", filter.c:79
@@ -290,7 +322,6 @@ struct filter_in *create_filter_input(unsigned int L, unsigned int M, enum filte
   }
   if (ok && N > KH_MAX_SMALL_N) ok = KH_HIP(hipMalloc(&im->d_tmp, N * sizeof(float2)));
   master->fwd_plan = im;
-  master->fd = -1;
   if (!ok) {
     delete_filter_input(master);
     return nullptr;
@@ -454,6 +485,11 @@ int execute_filter_output(struct filter_out *slave, int rotate) {
 int delete_filter_input(struct filter_in *master) { // filter.c:386
   if (master == nullptr) return 0;
   FilterInImpl *im = (FilterInImpl *)master->fwd_plan;
+  if (im && im->mapped_bytes) { // create_filter_input_file
+    munmap(master->fdomain, im->mapped_bytes);
+    master->fdomain = nullptr;
+  }
+  if (master->fd >= 0) close(master->fd);
   if (im) {
     if (im->stream) {
       hipStreamSynchronize(im->stream);
@@ -584,6 +620,54 @@ int set_filter(struct filter_out *slave, float low, float high, float kaiser_bet
   pthread_mutex_unlock(&slave->response_mutex);
   ka9q_hip_free(tmp);
   return 0;
+}
+
+// ------------------------------------------------------------------ filter.c:707-727
+struct notchfilter *notch_create(double f, float bw) {
+  struct notchfilter *nf = (struct notchfilter *)calloc(1, sizeof(struct notchfilter));
+  if (nf == nullptr) return nullptr;
+  nf->osc_phase.re = 1; // filter.c:712
+  nf->osc_phase.im = 0;
+  double sn, cs;
+  sincos(2 * M_PI * f, &sn, &cs); // cispi(2 f), dsp.h:37-50: a constant of the control path
+  nf->osc_step.re = cs;
+  nf->osc_step.im = sn;
+  nf->bw = bw;
+  return nf;
+}
+int kh_notch_block(struct notchfilter *nf, kh_cf32 *buf, int n) {
+  if (nf == nullptr || (buf == nullptr && n > 0) || n < 0) {
+    set_error("kh_notch_block: bad argument");
+    return -1;
+  }
+  if (ensure_init()) return -1;
+  if (n == 0) return 0;
+  hipStream_t st = default_stream();
+  hipPointerAttribute_t attr;
+  bool on_dev = hipPointerGetAttributes(&attr, buf) == hipSuccess && attr.type == hipMemoryTypeDevice;
+  (void)hipGetLastError();
+  char *scratch = nullptr; // state, then the samples when they come from the host
+  size_t const bytes = (size_t)n * sizeof(float2);
+  if (!KH_HIP(hipMalloc(&scratch, 256 + (on_dev ? 0 : bytes)))) return -1;
+  NotchState hs{nf->osc_phase.re, nf->osc_phase.im, nf->osc_step.re, nf->osc_step.im, nf->dcstate.re, nf->dcstate.im, nf->bw, 0};
+  float2 *d = on_dev ? reinterpret_cast<float2 *>(buf) : reinterpret_cast<float2 *>(scratch + 256);
+  bool ok = KH_HIP(hipMemcpyAsync(scratch, &hs, sizeof hs, hipMemcpyHostToDevice, st));
+  if (ok && !on_dev) ok = KH_HIP(hipMemcpyAsync(d, buf, bytes, hipMemcpyHostToDevice, st));
+  ok = ok && launch_notch(st, reinterpret_cast<NotchState *>(scratch), d, n) == 0;
+  ok = ok && KH_HIP(hipMemcpyAsync(&hs, scratch, sizeof hs, hipMemcpyDeviceToHost, st));
+  if (ok && !on_dev) ok = KH_HIP(hipMemcpyAsync(buf, d, bytes, hipMemcpyDeviceToHost, st));
+  ok = ok && KH_HIP(hipStreamSynchronize(st));
+  hipFree(scratch);
+  if (!ok) return -1;
+  nf->osc_phase.re = hs.pr;
+  nf->osc_phase.im = hs.pi;
+  nf->dcstate.re = hs.dr;
+  nf->dcstate.im = hs.di;
+  return 0;
+}
+kh_cf32 notch(struct notchfilter *nf, kh_cf32 s) {
+  if (nf == nullptr || kh_notch_block(nf, &s, 1)) s.re = s.im = NAN; // filter.c:720-721
+  return s;
 }
 
 // ------------------------------------------------------------------ decimate.h

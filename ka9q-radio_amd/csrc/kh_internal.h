@@ -224,6 +224,13 @@ int launch_make_kaiser(hipStream_t st, float *window_dev, int M, float beta);
 int launch_window_filter(hipStream_t st, float2 *resp_dev, int L, int M, float beta, int real_filter);
 int launch_brickwall(hipStream_t st, float2 *resp_dev, int ND, float low, float high, float gain);
 int launch_noise_gain(hipStream_t st, const float2 *resp_dev, int count, float scale, float *out_dev);
+// filter.c:719-727 over n samples in place; st: {phase, step, dcstate, bw} on the device, updated
+struct NotchState {
+  double pr, pi, sr, si;
+  float dr, di, bw;
+  int pad;
+};
+int launch_notch(hipStream_t st, NotchState *state, float2 *buf, int n);
 // decimate.c
 int launch_decimate(hipStream_t st, float *rails, size_t rail_stride, int nrails, int chunk, int log_decimate,
                     int stage_threshold, void *hb15_states, float *hb3_states);

@@ -20,7 +20,7 @@ KH_STAGES = ["ingest", "fft1", "fft2", "n0", "chan", "demod", "carry"]
 # every symbol include/ka9q_hip.h declares
 EXPORTS = [
     "ka9q_hip_init", "ka9q_hip_last_error", "ka9q_hip_alloc", "ka9q_hip_free",
-    "create_filter_input", "create_filter_output", "execute_filter_input", "execute_filter_output",
+    "create_filter_input", "create_filter_input_file", "notch_create", "notch", "kh_notch_block", "create_filter_output", "execute_filter_input", "execute_filter_output",
     "delete_filter_input", "delete_filter_output", "make_kaiser", "window_filter", "window_rfilter",
     "set_filter", "noise_gain", "hb15_block", "hb3_block", "kh_decimate_rails",
     "kh_bank_create", "kh_bank_destroy", "kh_bank_set_channel", "kh_bank_set_lo", "kh_bank_set_second_lo", "kh_bank_set_doppler", "kh_bank_write_input",
@@ -48,6 +48,15 @@ class PthreadMutex(C.Structure):  # glibc x86-64: 40 bytes, 8-byte aligned
 
 class PthreadCond(C.Structure):  # glibc x86-64: 48 bytes, 8-byte aligned
     _fields_ = [("_", C.c_longlong * 6)]
+
+
+class CF32(C.Structure):  # C's complex float, by value
+    _fields_ = [("re", C.c_float), ("im", C.c_float)]
+
+
+class NotchFilter(C.Structure):  # filter.h:97-103
+    _fields_ = [("phase_re", C.c_double), ("phase_im", C.c_double), ("step_re", C.c_double), ("step_im", C.c_double),
+                ("dc", CF32), ("bw", C.c_float)]
 
 
 class FilterIn(C.Structure):  # filter.h:55-68
@@ -112,6 +121,13 @@ def lib():
     L.ka9q_hip_free.argtypes = [C.c_void_p]
     L.create_filter_input.restype = C.POINTER(FilterIn)
     L.create_filter_input.argtypes = [C.c_uint, C.c_uint, C.c_int]
+    L.create_filter_input_file.restype = C.POINTER(FilterIn)
+    L.create_filter_input_file.argtypes = [C.c_uint, C.c_uint, C.c_int, C.c_char_p]
+    L.notch_create.restype = C.POINTER(NotchFilter)
+    L.notch_create.argtypes = [C.c_double, C.c_float]
+    L.notch.restype = CF32
+    L.notch.argtypes = [C.POINTER(NotchFilter), CF32]
+    L.kh_notch_block.argtypes = [C.POINTER(NotchFilter), C.c_void_p, C.c_int]
     L.create_filter_output.restype = C.POINTER(FilterOut)
     L.create_filter_output.argtypes = [C.POINTER(FilterIn), C.c_void_p, C.c_uint, C.c_int]
     L.execute_filter_input.argtypes = [C.POINTER(FilterIn)]
