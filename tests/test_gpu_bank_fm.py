@@ -11,19 +11,33 @@ from conftest import rel_rms
 pytestmark = pytest.mark.gpu
 
 
-def _run_pair(hip, L, M, D, fs, chans, x, nblocks_per_call, calls, flat=0, n0=False):
+def _run_pair(hip, L, M, D, fs, chans, x, nblocks_per_call, calls, flat=0, n0=False, referee=None):
+    """referee (tools/fuzz_bank.py): called as referee(field, ctx) for every comparison that is outside its bar; True
+    means the deviation has been shown to be the reference arithmetic's own (the sweep records it) and the REMAINING
+    comparisons still run; None (the fixed tests): any deviation fails at once."""
     C = len(chans)
     T = nblocks_per_call
     bank = hip.Bank(L, M, D, 1, C, T, fs, compute_n0=int(n0), n0_low=-5500.0, n0_high=5500.0)
     pipe = pipeline.Pipeline(L, M, D, fs, compute_n0=n0, n0_low=-5500.0, n0_high=5500.0)
     N = L + M - 1
+    rots = []
     for c, (k, *_rest) in enumerate(chans):
         rot = synth.rotate_for(k, 12500.0, N, fs)
+        rots.append(rot)
         kw = dict(rotate=rot, low=-5500.0, high=5500.0, kaiser_beta=3.0, flat=flat)
         bank.set_channel(c, demod=hip.KH_DEMOD_FM, **kw)
         pipe.add_channel(demod="fm", **kw)
     olen = L // D
     res = []
+
+    def check(ok, field, msg, **ctx):
+        if ok:
+            return True
+        if referee is not None and referee(field, dict(ctx, L=L, M=M, D=D, fs=fs, N=N, T=T, x=x, rots=rots, bank=bank,
+                                                         pipe=pipe, msg=msg)):
+            return False
+        raise AssertionError(msg)
+
     for call in range(calls):
         seg = x[call * T * L:(call + 1) * T * L]
         bank.write_input(0, seg)
@@ -40,14 +54,19 @@ def _run_pair(hip, L, M, D, fs, chans, x, nblocks_per_call, calls, flat=0, n0=Fa
                 assert rel_rms(g_spec0, pipe.spectrum(0)) < 1e-5
             assert abs(g_ist[b]["if_power"] - istat[0][0]) <= 1e-4 * istat[0][0]
             if n0:
-                assert abs(g_ist[b]["n0"] - istat[0][1]) <= 1e-4 * abs(istat[0][1]), (b, g_ist[b]["n0"], istat[0][1])
+                check(abs(g_ist[b]["n0"] - istat[0][1]) <= 1e-4 * abs(istat[0][1]), "n0",
+                      f'["n0"] block {b} call {call}: {g_ist[b]["n0"]} vs {istat[0][1]}', call=call, block=b,
+                      gpu=float(g_ist[b]["n0"]), oracle=float(istat[0][1]))
             for c in range(C):
                 y, audio, sig = outs[c]
                 sl = slice(b * olen, (b + 1) * olen)
                 err = rel_rms(g_bb[c][sl], y)
-                assert err < 1e-5, f"baseband ch {c} block {b} call {call}: {err:.2e}"
+                bb_ok = check(err < 1e-5, "baseband", f"baseband ch {c} block {b} call {call}: {err:.2e}", call=call, block=b,
+                              ch=c, gpu=g_bb[c][sl], oracle=y)
                 pcm_o = orc_scaleclip(audio)
                 d = np.abs(g_pcm[c][sl].astype(np.int32) - pcm_o.astype(np.int32))
+                # (a channel whose baseband deviation the referee has accepted is a noise-only channel with the squelch
+                # closed: its PCM is zeros on both sides and is still compared)
                 assert d.max() <= 1, f"pcm ch {c} block {b} call {call}: max diff {d.max()}"
                 assert np.allclose(g_aud[c][sl], audio, rtol=1e-4, atol=2e-5)
                 st = g_st[c][b]
@@ -58,7 +77,8 @@ def _run_pair(hip, L, M, D, fs, chans, x, nblocks_per_call, calls, flat=0, n0=Fa
                     # r = avg^2/var (fp32 sums in another order) moves a result of ~0.07 by a few 1e-5; the squelch
                     # compares snr with 4 (fm.c:73)
                     floor = 1e-4 if key == "snr" else 1e-12
-                    assert abs(st[key] - ref) <= 1e-4 * abs(ref) + floor, (key, c, b, st[key], ref)
+                    check(abs(st[key] - ref) <= 1e-4 * abs(ref) + floor, key, f"{key} ch {c} block {b} call {call}: {st[key]} vs {ref}",
+                          call=call, block=b, ch=c, gpu=float(st[key]), oracle=float(ref), y_oracle=y, bb_ok=bb_ok)
                 res.append((c, b, int(st["squelch_open"]), sig))
                 if st["squelch_open"] or sig["snr"] > 4:
                     for key in ("foffset", "pdeviation"):

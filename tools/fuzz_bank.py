@@ -4,7 +4,6 @@ GPU box): tools/fuzz_bank.py [cases] [seed].  Draws the transform size, decimati
 slots, amplitudes, tones, deviations, de-emphasis and compute_n0 at random and applies the bars of
 tests/test_gpu_bank_fm.py (_run_pair: baseband 1e-5, PCM +-1 LSB, status 1e-4).  Exit status 1 if any case fails."""
 import os
-import re
 import sys
 import time
 import traceback
@@ -32,23 +31,97 @@ def n0_float64(fd, N, low, high, fs):
     return avg / (float(N) * fs)
 
 
-def diagnose_n0(L, M, D, fs, x, T):
-    """First launch again with one channel: n0 of block 0 from the GPU, from the oracle's C restatement (the reference's
-    sequential fp32 sums) on the GPU's spectrum, and in float64."""
-    import ctypes as C
+def f64_baseband(ctx, ch):
+    """The channel's filter output for ctx's (call, block) in float64: the N-sample window, numpy's complex128 FFT, the
+    integer bin map of filter.c:276-289, the (fp32-designed) response, the backward transform, the last olen points."""
+    L, M, N, D, T, x = ctx["L"], ctx["M"], ctx["N"], ctx["D"], ctx["T"], ctx["x"]
+    g = ctx["call"] * T + ctx["block"]
+    lo, hi = g * L - (M - 1), g * L + L
+    w = np.zeros(N, np.complex128)
+    src = x[max(lo, 0):hi]
+    w[N - src.size:] = src
+    X = np.fft.fft(w)
+    ND = N // D
+    resp = ctx["pipe"].channels[ch].response(ND).astype(np.complex128)
+    m0 = (N - ND // 2 + 1 + ctx["rots"][ch]) % N
+    p = (ND // 2 + 1 + np.arange(ND)) % ND
+    m = (m0 + np.arange(ND)) % N
+    f = np.zeros(ND, np.complex128)
+    f[p] = resp[p] * X[m]
+    y = np.fft.ifft(f) * ND
+    return y[ND - L // D:]
 
+
+def f64_stats(y):
+    """fm.c:53-70 in float64: baseband power, r = mean(amplitude)^2 / variance, snr"""
     import orc
-    N = L + M - 1
-    bank = hip.Bank(L, M, D, 1, 1, T, fs, compute_n0=1, n0_low=-5500.0, n0_high=5500.0)
-    bank.set_channel(0, demod=hip.KH_DEMOD_FM, rotate=0, low=-5500.0, high=5500.0, kaiser_beta=3.0, flat=0)
-    bank.write_input(0, x[:T * L])
-    bank.execute(T)
-    g = float(bank.input_status(0, T)[0]["n0"])
-    fd = bank.spectrum(0, 0)
-    o = float(orc.lib().orc_compute_n0(fd.ctypes.data_as(C.c_void_p), N, -5500.0, 5500.0, fs))
-    t = n0_float64(fd, N, -5500.0, 5500.0, fs)
-    bank.close()
-    return g, o, t
+    amp = np.abs(y)
+    avg, var = amp.mean(), amp.var(ddof=1)
+    r = avg * avg / var
+    return float((amp ** 2).mean()), float(r), float(avg / np.sqrt(var)), lambda rr: max(0.0, float(orc.lib().orc_fm_snr(float(rr))))
+
+
+class Referee:
+    """Decides whether a deviation between the GPU and the oracle is the reference arithmetic's own (fp32 running sums,
+    fp32 transforms under strong neighbours, fm_snr where it is ill-conditioned) -- by an independent float64 evaluation
+    of the same quantity, never by magnitude alone: the GPU must be no further from float64 than a small multiple of the
+    oracle's own distance, or inside what float64 gives for an input perturbed by fp32 rounding."""
+
+    def __init__(self):
+        self.n0 = self.quiet = self.snr = self.bbp = 0
+        self.log = []
+        self.n0_chain = []  # smoothed float64 n0 of every block of the case so far
+
+    def __call__(self, field, ctx):
+        g, o = ctx["gpu"], ctx["oracle"]
+        if field == "n0":
+            # radio.c:422-465 and the smoothing of radio.c:199-202 in float64, block after block from the input itself
+            L, M, N, T, x = ctx["L"], ctx["M"], ctx["N"], ctx["T"], ctx["x"]
+            upto = ctx["call"] * T + ctx["block"]
+            while len(self.n0_chain) <= upto:
+                gblk = len(self.n0_chain)
+                lo, hi = gblk * L - (M - 1), gblk * L + L
+                w = np.zeros(N, np.complex128)
+                src = x[max(lo, 0):hi]
+                w[N - src.size:] = src
+                v = n0_float64(np.fft.fft(w), N, -5500.0, 5500.0, ctx["fs"])
+                self.n0_chain.append(v if not self.n0_chain else self.n0_chain[-1] + .005 * (v - self.n0_chain[-1]))
+            t = self.n0_chain[upto]
+            if abs(g - t) <= 2e-5 * t:  # the GPU agrees with exact arithmetic; the reference's fp32 running sums do not
+                self.n0 += 1
+                self.log.append(f"n0 block {upto}: gpu {g:.6e} float64 {t:.6e} oracle {o:.6e} (gpu-f64 {abs(g - t) / t:.1e}, oracle-f64 {abs(o - t) / t:.1e})")
+                return True
+            return False
+        y64 = f64_baseband(ctx, ctx["ch"])
+        if field == "baseband":
+            nrm = np.linalg.norm(y64)
+            eg, eo = np.linalg.norm(g - y64) / nrm, np.linalg.norm(o - y64) / nrm
+            if eg <= 1.5 * eo + 1e-6:  # the GPU is no further from exact arithmetic than the reference's own fp32 transform
+                self.quiet += 1
+                self.log.append(f"baseband ch {ctx['ch']}: gpu-f64 {eg:.2e}, oracle-f64 {eo:.2e} of the channel's level")
+                return True
+            return False
+        bbp, r, avg_over_sigma, snr_of = f64_stats(y64)
+        if field == "bb_power":
+            if abs(g - bbp) <= 3 * abs(o - bbp) + 1e-6 * bbp:
+                self.bbp += 1
+                self.log.append(f"bb_power ch {ctx['ch']}: gpu-f64 {abs(g - bbp) / bbp:.1e}, oracle-f64 {abs(o - bbp) / bbp:.1e}")
+                return True
+            return False
+        if field == "snr":
+            t = snr_of(r)
+            # what float64 gives when the baseband moves by fp32 rounding (3e-6 of its level): r = avg^2/var moves by
+            # that times avg/sigma through the variance (fm.c:63-67 is a two-pass variance; the amplification is in the
+            # quotient, not in a cancellation)
+            eta = 3e-6 * max(1.0, avg_over_sigma)
+            lo_, hi_ = sorted((snr_of(r * (1 - eta)), snr_of(r * (1 + eta))))
+            if abs(g - t) <= 3 * abs(o - t) or lo_ - 1e-6 <= g <= hi_ + 1e-6:
+                self.snr += 1
+                self.log.append(f"snr ch {ctx['ch']}: gpu {g:.6g} oracle {o:.6g} float64 {t:.6g}, float64 under fp32-sized "
+                                f"perturbation [{lo_:.6g}, {hi_:.6g}] (avg/sigma {avg_over_sigma:.1f})")
+                return True
+            return False
+        return False
 
 
 def main():
@@ -91,44 +164,25 @@ def main():
         x = synth.wideband_fm(0, T * calls * L, fs, N, sigs)
         if os.environ.get("FUZZ_ONLY"):
             print("carriers", sigs, "empty", empty, flush=True)
+        ref = Referee()
         try:
-            _run_pair(hip, L, M, D, fs, sigs + empty, x, T, calls, flat=flat, n0=n0)
-            print(f"[{k}] ok  {tag}", flush=True)
+            _run_pair(hip, L, M, D, fs, sigs + empty, x, T, calls, flat=flat, n0=n0, referee=ref)
+            if ref.log:
+                explained += ref.n0
+                quiet += ref.quiet
+                near_thr += ref.snr
+                cancel += ref.bbp
+                print(f"[{k}] ok* {tag}: every other comparison inside its bar; judged against float64:", flush=True)
+                for line in ref.log:
+                    print("       " + line, flush=True)
+            else:
+                print(f"[{k}] ok  {tag}", flush=True)
         except AssertionError as e:
-            tb = traceback.format_exc(limit=2)
-            if '["n0"]' in tb:
-                g, o, t = diagnose_n0(L, M, D, fs, x, T)
-                if abs(g - t) <= 2e-5 * t:  # the GPU agrees with exact arithmetic; the reference's running sums do not
-                    explained += 1
-                    print(f"[{k}] n0  {tag}: gpu {g:.6e} float64 {t:.6e} oracle {o:.6e} (gpu-f64 {abs(g - t) / t:.1e}, "
-                          f"oracle-f64 {abs(o - t) / t:.1e})", flush=True)
-                    continue
-            m = re.match(r"baseband ch (\d+) block \d+ call \d+: ([0-9.e+-]+)", str(e))
-            if m and int(m.group(1)) >= len(sigs) and float(m.group(2)) < 1e-4:
-                # a noise-only channel 50-60 dB below the carriers elsewhere in the band: what either fp32 transform
-                # rounds off the strong bins is spread over all bins and reaches 1e-5 of such a channel's own level
-                quiet += 1
-                print(f"[{k}] dyn {tag}: noise-only channel {m.group(1)} at {m.group(2)} of its own level", flush=True)
-                continue
-            if "'snr'" in str(e):
-                # fm_snr just above its threshold (fm.c:190-205): the fixed-point iteration contracts with a ratio close to
-                # 1 there, so the last bit of r = avg^2/var moves a result of ~0.1 by 1e-4
-                g, o = float(e.args[0][3]), float(e.args[0][4])
-                if o > 1e4 and abs(g - o) < 1e-3 * o:
-                    # a carrier 60 dB over the noise: fm.c:53-70 takes the variance as E[a^2] - E[a]^2, which cancels
-                    # to its last digits there, and snr = f(avg^2/var) carries that
-                    cancel += 1
-                    print(f"[{k}] snr {tag}: gpu {g:.1f} oracle {o:.1f} (variance cancellation at snr > 1e4)", flush=True)
-                    continue
-                if o < 0.5 and abs(g - o) < 5e-4:
-                    near_thr += 1
-                    print(f"[{k}] snr {tag}: gpu {g:.6f} oracle {o:.6f} (noise-only block at fm_snr's threshold)", flush=True)
-                    continue
             bad += 1
             print(f"[{k}] BAD {tag}: {str(e)[:200]}", flush=True)
-            print(tb, flush=True)
-    print(f"{cases} cases, {bad} bad; explained: {explained} n0 (the reference's fp32 running sums against float64), "
-          f"{near_thr} snr at fm_snr's threshold, {quiet} noise-only channels under strong carriers, {cancel} snr above 1e4; {time.time() - t0:.0f} s")
+            print(traceback.format_exc(limit=2), flush=True)
+    print(f"{cases} cases, {bad} bad; deviations judged against an independent float64 evaluation and found to be the reference "
+          f"arithmetic's own: {explained} n0, {near_thr} snr, {quiet} baseband, {cancel} bb_power; {time.time() - t0:.0f} s")
     return 1 if bad else 0
 
 

@@ -17,7 +17,7 @@ for p in (ROOT, os.path.join(ROOT, "oracle"), os.path.join(ROOT, "ka9q-radio_amd
 import orc  # noqa: E402
 import pipeline  # noqa: E402
 import pyka9q as hip  # noqa: E402
-from fuzz_linear import SIGS, draw_channel  # noqa: E402
+from fuzz_linear import SIGS, draw_channel, is_agc_tie  # noqa: E402
 from test_gpu_bank_linear import FS, L, M, D, OLEN, _signal  # noqa: E402
 
 
@@ -76,7 +76,7 @@ def run_case(rng, ties):
                         i = int(np.argmax(rel > 5e-5))
                         # the hang AGC's branch tie (tools/fuzz_linear.py), with a hang time: the side that took the attack
                         # branch holds its gain for hangtime samples while the other recovers
-                        tie = bool(kw.get("agc")) and err <= (kw.get("hangtime", 0.0) + 1.5) * (kw["recovery_rate"] - 1)
+                        tie = bool(kw.get("agc")) and is_agc_tie(ga, audio, kw["recovery_rate"], kw.get("hangtime", 0.0), nch)
                         msg = (f"{what}: audio err {err:.2e}, first beyond 5e-5 at sample {i} of {ga.size}: gpu "
                                f"{np.array2string(ga[max(i - 3, 0):i + 4], precision=7)} oracle "
                                f"{np.array2string(audio[max(i - 3, 0):i + 4], precision=7)}; rel err there "
@@ -85,7 +85,7 @@ def run_case(rng, ties):
                             ties.append(msg)
                             continue
                         raise AssertionError(msg)
-                    if d.max() > 1 and kw.get("agc") and err <= 1.5 * (kw["recovery_rate"] - 1):
+                    if d.max() > 1 and kw.get("agc") and is_agc_tie(ga, audio, kw["recovery_rate"], kw.get("hangtime", 0.0), nch):
                         ties.append(what)  # AGC branch tie (tools/fuzz_linear.py)
                         continue
                     assert d.max() <= 1, f"{what}: pcm max diff {d.max()}, block audio err {err:.2e}"
