@@ -228,6 +228,17 @@ int kh_bank_set_gain(kh_bank *, unsigned int input, float gain_factor);
  * the GPU.  After filling nblocks*L samples call kh_bank_commit_input. */
 int kh_bank_raw_device_ptr(kh_bank *, unsigned int input, void **dptr, size_t *capacity_samples);
 int kh_bank_commit_input(kh_bank *, unsigned int input, size_t count);
+/* Streaming ingest: proc_samples' hand-over (radio.c:132-191) when the samples arrive in host memory.  The library
+ * owns a pinned host ring of `depth` slots (each max_blocks*L samples of the wire format, per input).  The producer
+ * asks for the current slot of each input (kh_bank_stream_slot: blocks only if the transfer that last left that slot,
+ * depth submits ago, is still running), writes nblocks*L samples there -- e.g. recvfrom() straight into it -- and calls
+ * kh_bank_stream_submit: a hipMemcpyAsync on a copy stream of its own into one of two device raw rings, and
+ * kh_bank_execute(nblocks) ordered behind it.  Submit returns at once; the transfer of launch k+1 overlaps launch k.
+ * Do not mix with kh_bank_write_input / kh_bank_commit_input on the same bank while the stream is open. */
+int kh_bank_stream_open(kh_bank *, unsigned int depth);   /* 2..64 */
+void *kh_bank_stream_slot(kh_bank *, unsigned int input, size_t *capacity_samples);
+int kh_bank_stream_submit(kh_bank *, unsigned int nblocks);
+int kh_bank_stream_close(kh_bank *);                      /* waits for everything in flight; NULL -> 0 */
 /* one pass of the hot path over nblocks (<= max_blocks) blocks of every input: convert + mix (a7),
  * forward FFT (a2), compute_n0 (a8), per channel bin-select x response x IFFT (a4), demod (a9-a12),
  * scaleclip (a14).  Asynchronous on the bank's stream; kh_bank_sync waits.  0 or -1. */
@@ -237,6 +248,8 @@ int kh_bank_sync(kh_bank *);
 int kh_bank_read_baseband(kh_bank *, unsigned int ch, kh_cf32 *out, size_t nsamples);       /* nblocks*olen */
 int kh_bank_read_pcm(kh_bank *, unsigned int ch, int16_t *out, size_t nwords);               /* nblocks*olen*channels */
 int kh_bank_read_audio(kh_bank *, unsigned int ch, float *out, size_t nwords);               /* float before scaleclip */
+/* the PCM of ALL channels in one transfer: channel ch at out + ch*nwords */
+int kh_bank_read_pcm_all(kh_bank *, int16_t *out, size_t nwords);
 int kh_bank_read_status(kh_bank *, unsigned int ch, struct kh_status *out, size_t nblocks);
 int kh_bank_read_input_status(kh_bank *, unsigned int input, struct kh_input_status *out, size_t nblocks);
 int kh_bank_read_spectrum(kh_bank *, unsigned int input, unsigned int block, kh_cf32 *out);  /* N bins */

@@ -133,6 +133,18 @@ struct kh_bank {
   // measured on MI355X (tools/hostbound.py): replaying two small graphs costs the host more than their handful of
   // launches, so graphs are off unless asked for
   int use_graph = 0;
+  // streaming ingest (kh_bank_stream_*): a pinned host ring of `stream_depth` slots per input, fed to two device raw
+  // rings by hipMemcpyAsync on a copy stream of its own, so that the transfer of launch k+1 runs beside launch k
+  unsigned char *h_ring = nullptr;
+  size_t h_slot_bytes = 0;        // bytes of one input's slot (max_blocks*L samples of the wire format)
+  unsigned stream_depth = 0;
+  unsigned long long stream_k = 0; // submits so far
+  hipStream_t copy = nullptr;
+  std::vector<hipEvent_t> ev_h2d;  // per host slot: the copy out of it has completed
+  std::vector<char> ev_h2d_rec;
+  unsigned char *d_raw_buf[2] = {nullptr, nullptr}; // [0] is d_raw as created
+  hipEvent_t ev_raw_free[2] = {};  // the front half that read this device ring has run
+  bool raw_free_rec[2] = {false, false};
   // profiling
   bool profiling = false;
   hipEvent_t ev[KH_STAGE_COUNT + 2] = {};
@@ -152,10 +164,12 @@ static void drop_graphs(kh_bank *b) { // anything a captured launch baked in has
 
 extern "C" {
 
+int kh_bank_stream_close(kh_bank *b);
 int kh_bank_destroy(kh_bank *b) {
   if (!b) return 0;
   if (b->stream) hipStreamSynchronize(b->stream);
   if (b->front) hipStreamSynchronize(b->front);
+  kh_bank_stream_close(b);
   drop_graphs(b);
   for (int k = 0; k < kh_bank::MAX_SLOTS; k++) {
     if (b->d_spec[k]) hipFree(b->d_spec[k]);
@@ -491,6 +505,113 @@ int kh_bank_commit_input(kh_bank *b, unsigned int input, size_t count) {
   if (count > (size_t)b->T * b->cfg.L) return -1;
   b->fill[input] = count;
   return 0;
+}
+
+// ---- streaming ingest: what replaces proc_samples' per-packet loop (radio.c:132-191) when the samples arrive on the
+// host.  The producer (the thread that owns the socket) writes wire-format samples straight into a pinned slot, the
+// library moves the slot to the device on a copy stream and runs the launch behind it.
+int kh_bank_stream_open(kh_bank *b, unsigned int depth) {
+  if (!b || depth < 2 || depth > 64) {
+    set_error("kh_bank_stream_open: depth must be in [2, 64]");
+    return -1;
+  }
+  if (b->stream_depth) {
+    set_error("kh_bank_stream_open: already open");
+    return -1;
+  }
+  size_t const P = b->P;
+  b->h_slot_bytes = b->raw_stride;
+  bool ok = KH_HIP(hipHostMalloc((void **)&b->h_ring, (size_t)depth * P * b->h_slot_bytes, hipHostMallocDefault));
+  ok = ok && KH_HIP(hipStreamCreateWithFlags(&b->copy, hipStreamNonBlocking));
+  b->d_raw_buf[0] = b->d_raw;
+  ok = ok && KH_HIP(hipMalloc((void **)&b->d_raw_buf[1], P * b->raw_stride));
+  ok = ok && KH_HIP(hipMemset(b->d_raw_buf[1], 0, P * b->raw_stride));
+  b->ev_h2d.assign(depth, nullptr);
+  b->ev_h2d_rec.assign(depth, 0);
+  for (auto &e : b->ev_h2d) ok = ok && KH_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+  for (auto &e : b->ev_raw_free) ok = ok && KH_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+  b->raw_free_rec[0] = b->raw_free_rec[1] = false;
+  b->stream_k = 0;
+  b->stream_depth = depth;
+  if (!ok) {
+    kh_bank_stream_close(b);
+    return -1;
+  }
+  return 0;
+}
+int kh_bank_stream_close(kh_bank *b) {
+  if (!b) return 0;
+  if (b->copy) hipStreamSynchronize(b->copy);
+  if (b->front) hipStreamSynchronize(b->front);
+  if (b->stream) hipStreamSynchronize(b->stream);
+  for (auto &e : b->ev_h2d)
+    if (e) hipEventDestroy(e);
+  b->ev_h2d.clear();
+  for (auto &e : b->ev_raw_free) {
+    if (e) hipEventDestroy(e);
+    e = nullptr;
+  }
+  if (b->d_raw_buf[0]) b->d_raw = b->d_raw_buf[0]; // what kh_bank_destroy frees
+  if (b->d_raw_buf[1]) hipFree(b->d_raw_buf[1]);
+  b->d_raw_buf[0] = b->d_raw_buf[1] = nullptr;
+  if (b->h_ring) hipHostFree(b->h_ring);
+  b->h_ring = nullptr;
+  if (b->copy) hipStreamDestroy(b->copy);
+  b->copy = nullptr;
+  b->stream_depth = 0;
+  return 0;
+}
+void *kh_bank_stream_slot(kh_bank *b, unsigned int input, size_t *capacity_samples) {
+  if (!b || !b->stream_depth || input >= (unsigned)b->P) {
+    set_error("kh_bank_stream_slot: stream not open or input out of range");
+    return nullptr;
+  }
+  unsigned const slot = (unsigned)(b->stream_k % b->stream_depth);
+  // the transfer that last left this slot (depth submits ago) must have completed before the producer overwrites it
+  if (b->ev_h2d_rec[slot] && !KH_HIP(hipEventSynchronize(b->ev_h2d[slot]))) return nullptr;
+  if (capacity_samples) *capacity_samples = (size_t)b->T * b->cfg.L;
+  return b->h_ring + ((size_t)slot * b->P + input) * b->h_slot_bytes;
+}
+int kh_bank_stream_submit(kh_bank *b, unsigned int nblocks) {
+  if (!b || !b->stream_depth) {
+    set_error("kh_bank_stream_submit: stream not open");
+    return -1;
+  }
+  if (nblocks == 0 || nblocks > (unsigned)b->T) {
+    set_error("kh_bank_stream_submit: nblocks %u outside [1, %d]", nblocks, b->T);
+    return -1;
+  }
+  unsigned const slot = (unsigned)(b->stream_k % b->stream_depth);
+  int const dev = (int)(b->stream_k & 1);
+  size_t const bytes = payload_bytes(b->cfg.payload, (size_t)nblocks * b->cfg.L);
+  // the front half that last read this device ring (two submits ago) runs before the copy overwrites it
+  if (b->raw_free_rec[dev] && !KH_HIP(hipStreamWaitEvent(b->copy, b->ev_raw_free[dev], 0))) return -1;
+  for (int i = 0; i < b->P; i++)
+    if (!KH_HIP(hipMemcpyAsync(b->d_raw_buf[dev] + (size_t)i * b->raw_stride,
+                               b->h_ring + ((size_t)slot * b->P + i) * b->h_slot_bytes, bytes, hipMemcpyHostToDevice, b->copy)))
+      return -1;
+  if (!KH_HIP(hipEventRecord(b->ev_h2d[slot], b->copy))) return -1;
+  b->ev_h2d_rec[slot] = 1;
+  // whichever stream the front half takes (profiling passes put it on the back stream) waits for the samples
+  if (!KH_HIP(hipStreamWaitEvent(b->front, b->ev_h2d[slot], 0)) || !KH_HIP(hipStreamWaitEvent(b->stream, b->ev_h2d[slot], 0)))
+    return -1;
+  b->d_raw = b->d_raw_buf[dev];
+  for (int i = 0; i < b->P; i++) b->fill[i] = (size_t)nblocks * b->cfg.L;
+  int const rc = kh_bank_execute(b, nblocks);
+  if (rc) return rc;
+  hipStream_t const fs = (b->profiling || !b->pipeline) ? b->stream : b->front;
+  if (!KH_HIP(hipEventRecord(b->ev_raw_free[dev], fs))) return -1;
+  b->raw_free_rec[dev] = true;
+  b->stream_k++;
+  return 0;
+}
+// PCM of every channel of the last launch in one transfer: out[ch*nwords .. ] (host memory); synchronises
+int kh_bank_read_pcm_all(kh_bank *b, int16_t *out, size_t nwords) {
+  if (!b || !out || nwords > b->pcm_stride) return -1;
+  if (!KH_HIP(hipMemcpy2DAsync(out, nwords * sizeof(int16_t), b->d_pcm, b->pcm_stride * sizeof(int16_t), nwords * sizeof(int16_t),
+                               b->C, hipMemcpyDeviceToHost, b->stream)))
+    return -1;
+  return KH_HIP(hipStreamSynchronize(b->stream)) ? 0 : -1;
 }
 
 static int upload_channels(kh_bank *b) {

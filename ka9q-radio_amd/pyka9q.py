@@ -25,6 +25,7 @@ EXPORTS = [
     "set_filter", "noise_gain", "hb15_block", "hb3_block", "kh_decimate_rails",
     "kh_bank_create", "kh_bank_destroy", "kh_bank_set_channel", "kh_bank_set_lo", "kh_bank_set_second_lo", "kh_bank_set_doppler", "kh_bank_write_input",
     "kh_bank_write_zeros", "kh_bank_set_gain", "kh_bank_raw_device_ptr", "kh_bank_commit_input",
+    "kh_bank_stream_open", "kh_bank_stream_slot", "kh_bank_stream_submit", "kh_bank_stream_close", "kh_bank_read_pcm_all",
     "kh_bank_execute", "kh_bank_sync", "kh_bank_read_baseband", "kh_bank_read_pcm", "kh_bank_read_audio",
     "kh_bank_read_status", "kh_bank_read_input_status", "kh_bank_read_spectrum", "kh_bank_read_response",
     "kh_bank_pcm_device_ptr", "kh_bank_keep_audio", "kh_bank_keep_baseband", "kh_bank_use_graph", "kh_bank_stream", "kh_bank_profile", "kh_bank_stage_times",
@@ -160,6 +161,12 @@ def lib():
     L.kh_bank_commit_input.argtypes = [C.c_void_p, C.c_uint, C.c_size_t]
     L.kh_bank_execute.argtypes = [C.c_void_p, C.c_uint]
     L.kh_bank_sync.argtypes = [C.c_void_p]
+    L.kh_bank_stream_open.argtypes = [C.c_void_p, C.c_uint]
+    L.kh_bank_stream_slot.restype = C.c_void_p
+    L.kh_bank_stream_slot.argtypes = [C.c_void_p, C.c_uint, C.POINTER(C.c_size_t)]
+    L.kh_bank_stream_submit.argtypes = [C.c_void_p, C.c_uint]
+    L.kh_bank_stream_close.argtypes = [C.c_void_p]
+    L.kh_bank_read_pcm_all.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
     for name in ("kh_bank_read_baseband", "kh_bank_read_pcm", "kh_bank_read_audio", "kh_bank_read_status",
                  "kh_bank_read_input_status"):
         getattr(L, name).argtypes = [C.c_void_p, C.c_uint, C.c_void_p, C.c_size_t]
@@ -373,6 +380,31 @@ class Bank:
         out = np.empty(nblocks * self.olen * self.nch.get(ch, 1), np.int16)
         _check(self.lib.kh_bank_read_pcm(self.h, ch, out.ctypes.data, out.size), "kh_bank_read_pcm")
         return out
+
+    def pcm_all(self, nblocks, out=None):
+        """PCM of every channel (mono banks) in one transfer: array [C, nblocks*olen]"""
+        nw = nblocks * self.olen
+        if out is None:
+            out = np.empty((self.C, nw), np.int16)
+        _check(self.lib.kh_bank_read_pcm_all(self.h, out.ctypes.data, nw), "kh_bank_read_pcm_all")
+        return out
+
+    def stream_open(self, depth):
+        _check(self.lib.kh_bank_stream_open(self.h, depth), "kh_bank_stream_open")
+
+    def stream_slot(self, inp, dtype, count):
+        """numpy view of the first `count` items of the pinned slot the next submit will transfer for input `inp`"""
+        cap = C.c_size_t()
+        p = self.lib.kh_bank_stream_slot(self.h, inp, C.byref(cap))
+        if not p:
+            raise RuntimeError("kh_bank_stream_slot: " + last_error())
+        return _as_np(p, count, dtype)
+
+    def stream_submit(self, nblocks):
+        _check(self.lib.kh_bank_stream_submit(self.h, nblocks), "kh_bank_stream_submit")
+
+    def stream_close(self):
+        _check(self.lib.kh_bank_stream_close(self.h), "kh_bank_stream_close")
 
     def audio(self, ch, nblocks):
         out = np.empty(nblocks * self.olen * self.nch.get(ch, 1), np.float32)

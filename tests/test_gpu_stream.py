@@ -1,0 +1,65 @@
+"""Streaming ingest (kh_bank_stream_*): wire-format samples written into the library's pinned host ring and moved to the
+device by hipMemcpyAsync on a copy stream (the north_star's host side; replaces proc_samples' per-packet loop,
+radio.c:132-191).  Same kernels, same samples as kh_bank_write_input + kh_bank_execute, so every result must be
+bit-identical -- whatever the ring depth, with several submits in flight and with launches of different lengths."""
+import numpy as np
+import pytest
+
+import synth
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("payload_name,depth", [("KH_PT_IQ16LE", 2), ("KH_PT_IQ16LE", 4), ("KH_PT_CF32", 3)])
+def test_stream_matches_write_input(hip, payload_name, depth):
+    fs, L, M, D, C, T = 8_000_000, 131072, 131073, 256, 6, 3
+    N = L + M - 1
+    payload = getattr(hip, payload_name)
+    sigs = [(k - 3, 0.03 + 0.01 * k, 300.0 + 60 * k, 2500.0) for k in range(C)]
+    launches = [3, 1, 2, 3, 3, 2, 1, 3]  # blocks per submit
+    total = sum(launches)
+    x = synth.wideband_fm(9, total * L, fs, N, sigs)
+    if payload == hip.KH_PT_IQ16LE:  # IQ_PT: interleaved int16, radio.c:159-167
+        raw = np.empty(2 * x.size, np.int16)
+        raw[0::2] = np.clip(np.rint(x.real * 32767 * 4), -32768, 32767)
+        raw[1::2] = np.clip(np.rint(x.imag * 32767 * 4), -32768, 32767)
+        per_sample = 2
+    else:
+        raw = np.ascontiguousarray(x, np.complex64)
+        per_sample = 1
+    banks = []
+    for _ in range(2):
+        b = hip.Bank(L, M, D, 1, C, T, fs, payload=payload, compute_n0=1, n0_low=-5500.0, n0_high=5500.0)
+        for c, (k, *_r) in enumerate(sigs):
+            b.set_channel(c, demod=hip.KH_DEMOD_FM, rotate=synth.rotate_for(k, 12500.0, N, fs), low=-5500.0, high=5500.0,
+                          kaiser_beta=3.0)
+        banks.append(b)
+    ref, st = banks
+    want = []
+    pos = 0
+    for nb in launches:
+        ref.write_input(0, raw[pos * per_sample:(pos + nb * L) * per_sample], count=nb * L)
+        ref.execute(nb)
+        want.append((ref.pcm_all(nb).copy(), ref.input_status(0, nb).tobytes(), [ref.status(c, nb).tobytes() for c in range(C)]))
+        pos += nb * L
+    st.stream_open(depth)
+    pos = 0
+    got_last = None
+    for j, nb in enumerate(launches):
+        slot = st.stream_slot(0, raw.dtype, nb * L * per_sample)
+        slot[:] = raw[pos * per_sample:(pos + nb * L) * per_sample]
+        st.stream_submit(nb)  # returns at once
+        pos += nb * L
+        if j % 3 == 2 or j == len(launches) - 1:  # read back now and then: several submits are in flight in between
+            pcm = st.pcm_all(nb)
+            assert np.array_equal(pcm, want[j][0]), j
+            assert st.input_status(0, nb).tobytes() == want[j][1], j
+            assert [st.status(c, nb).tobytes() for c in range(C)] == want[j][2], j
+            got_last = pcm
+    assert got_last is not None and np.abs(got_last).max() > 100
+    st.stream_close()
+    # after closing, the plain write_input path works again on the same bank
+    st.write_input(0, raw[:L * per_sample], count=L)
+    st.execute(1)
+    for b in banks:
+        b.close()
