@@ -11,10 +11,20 @@ The raw I/Q of the step is resident in HBM before the timed region; nothing cros
 Before the W warm-up steps a fixed 0.25 s of untimed steps lets the GPU leave its idle clocks (KA9Q_BENCH_PREWARM_S
 overrides it; the counter passes of tools/profile_set.sh set 0); the K timed steps and the barriers are as the contract says.
 
-N > 1 is launched by torch.distributed.run, one rank per GPU: channels shard disjointly, every GPU recomputes
-the forward FFT of the same stream (SURVEY.md 8(e) option A); there is no data-path collective.
+After the headline region (rank 0, one GPU; all of it outside the timed region and reported as extra keys of the one
+JSON line): `shapes` -- the other BASELINE configurations as one GPU sees them (config 4's per-GPU share at 64 MS/s /
+N = 2^20, config 3's mixed AM/FM/SSB share at 20 MS/s, config 5's 256 PLL pipelines), each with its step time, its
+SURVEY.md 8(d) bytes and the fraction of the HBM roofline those amount to; `realtime` -- BASELINE metric (i): the whole
+8 MS/s raster (640 channels) fed block by block in real time from the library's pinned host ring through hipMemcpyAsync
+(s16le wire format), 1000 consecutive blocks, plus the same path unpaced for the PCIe-inclusive rate; `cpu_baseline` --
+the oracle on the host cores, one thread and all the box's cores.
+
+N > 1 is launched by torch.distributed.run, one rank per GPU: channels shard disjointly and contiguously in frequency
+(ka9q-radio_amd/shard.py), every GPU recomputes the forward FFT of the same stream (SURVEY.md 8(e) option A); there is
+no data-path collective.
 """
 import argparse
+import glob
 import json
 import os
 import sys
@@ -24,48 +34,80 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.join(ROOT, "ka9q-radio_amd"))
+import workloads  # noqa: E402
 
-FS, L, M, D = 8_000_000, 131072, 131073, 256
-N = L + M - 1
-ND = N // D
-OLEN = L // D
+SH = workloads.CONFIG2
+FS, L, M, D, N, ND, OLEN = SH.fs, SH.L, SH.M, SH.D, SH.N, SH.ND, SH.olen
 C = 64
 T = 32
 HBM_PEAK_GBPS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: 8 TB/s spec
 
 
-def channel_plan(rank):
-    """64 channels per GPU on a 12.5 kHz raster; rank r owns k = -32+64r .. 31+64r (contiguous in frequency)."""
-    import synth
-    ks = [k + 64 * rank for k in range(-32, 32)]
-    plan = []
-    for j, k in enumerate(ks):
-        amp = 0.01 * (10.0 ** (j / 63.0))  # 0.01 .. 0.1 log spaced
-        plan.append((k, amp, 300.0 + 50.0 * (j % 64), 2500.0))
-    return plan, [synth.rotate_for(k, 12500.0, N, FS) for k in ks]
-
-
-def make_input_torch(plan, device):
-    """noise + one NBFM carrier per channel, T*L samples, generated on the GPU (setup, not timed)."""
+def make_wideband_torch(shape, plan, nsamp, device, seed=0x6B613971, max_signals=96):
+    """noise (sigma 0.01 per rail) + the plan's carriers, nsamp samples at the wideband rate, generated on the GPU (setup,
+    not timed).  NBFM / AM / two-tone USB as ka9q-radio_amd/synth.py defines them.  Only the first `max_signals` channels
+    (evenly spread over the plan) carry a signal when the plan is larger: the arithmetic does not depend on it and the
+    set-up stays short; the others demodulate noise (squelch closed / AGC at full gain)."""
     import torch
     g = torch.Generator(device=device)
-    g.manual_seed(0x6B613971)
-    n = T * L
-    x = torch.randn(n, 2, device=device, generator=g, dtype=torch.float32) * 0.01
-    t = torch.arange(n, device=device, dtype=torch.float64) / FS
-    import synth
-    for (k, amp, tone, dev) in plan:
-        fc = synth.rotate_for(k, 12500.0, N, FS) * FS / N
-        ph = 2 * np.pi * fc * t + (dev / tone) * torch.sin(2 * np.pi * tone * t) + 0.1 * k
+    g.manual_seed(seed)
+    x = torch.randn(nsamp, 2, device=device, generator=g, dtype=torch.float32) * 0.01
+    t = torch.arange(nsamp, device=device, dtype=torch.float64) / shape.fs
+    step = max(1, len(plan) // max_signals)
+    for ch in plan[::step]:
+        fc = ch["rotate"] * shape.fs / shape.N
+        if ch["kind"] == "fm":
+            ph = 2 * np.pi * fc * t + (ch["deviation"] / ch["tone"]) * torch.sin(2 * np.pi * ch["tone"] * t) + 0.1 * ch["k"]
+            env = ch["amp"]
+        elif ch["kind"] == "am":
+            ph = 2 * np.pi * fc * t + 0.3
+            env = (ch["amp"] * (1.0 + ch["depth"] * torch.cos(2 * np.pi * ch["tone"] * t))).to(torch.float32)
+        else:  # usb two-tone: sum of two carriers
+            for f in (700.0, 1900.0):
+                p2 = torch.remainder(2 * np.pi * (fc + f) * t, 2 * np.pi).to(torch.float32)
+                x[:, 0] += 0.5 * ch["amp"] * torch.cos(p2)
+                x[:, 1] += 0.5 * ch["amp"] * torch.sin(p2)
+            continue
         ph = torch.remainder(ph, 2 * np.pi).to(torch.float32)
-        x[:, 0] += amp * torch.cos(ph)
-        x[:, 1] += amp * torch.sin(ph)
+        x[:, 0] += env * torch.cos(ph)
+        x[:, 1] += env * torch.sin(ph)
     return x.contiguous()
 
 
+def make_pipelines_torch(shape, plan, nsamp, device, seed=5):
+    """config 5: one 192 kS/s input per pipeline, a DSB signal with (CAM) or without (`square`) carrier at the IF, swept
+    by (f0, fdot); [P, nsamp, 2] float32"""
+    import torch
+    g = torch.Generator(device=device)
+    g.manual_seed(seed)
+    P = len(plan)
+    x = torch.randn(P, nsamp, 2, device=device, generator=g, dtype=torch.float32) * 0.001
+    t = (torch.arange(nsamp, device=device, dtype=torch.float64) / shape.fs)[None, :]
+    f0 = torch.tensor([ch["if_hz"] + ch["f0"] for ch in plan], device=device, dtype=torch.float64)[:, None]
+    fd = torch.tensor([ch["fdot"] for ch in plan], device=device, dtype=torch.float64)[:, None]
+    carrier = torch.tensor([0.0 if ch["square"] else 1.0 for ch in plan], device=device, dtype=torch.float32)[:, None]
+    ph = torch.remainder(2 * np.pi * (f0 * t + 0.5 * fd * t * t), 2 * np.pi).to(torch.float32)
+    env = 0.05 * (carrier + 0.5 * torch.cos(2 * np.pi * 400.0 * t).to(torch.float32))
+    x[:, :, 0] += env * torch.cos(ph)
+    x[:, :, 1] += env * torch.sin(ph)
+    return x.contiguous()
+
+
+def build_bank(pyka9q, shape, plan, nblocks, payload=None, compute_n0=1):
+    ids = {"fm": pyka9q.KH_DEMOD_FM, "linear": pyka9q.KH_DEMOD_LINEAR}
+    bank = pyka9q.Bank(shape.L, shape.M, shape.D, shape.P, len(plan), nblocks, shape.fs,
+                       payload=pyka9q.KH_PT_CF32 if payload is None else payload, compute_n0=compute_n0, n0_low=-5500.0, n0_high=5500.0)
+    bank.keep_audio(0)
+    if all(ch["demod"] == "fm" for ch in plan):
+        bank.keep_baseband(0)  # FM: filter output -> discriminator inside one kernel; PCM + status are the outputs
+    for c, ch in enumerate(plan):
+        bank.set_channel(c, demod=ids[ch["demod"]], **workloads.channel_kwargs(ch))
+    return bank
+
+
 def stage_bytes(bincount, n0_rides):
-    """algorithmic bytes per launch of each stage (DESIGN.md 'Kernels'): what the kernel must read + write.
-    fft1 = kh_fft_cols reading the raw ring itself (8 B/sample cf32, N samples per block window) and writing the
+    """algorithmic bytes per launch of each stage of the headline shape (DESIGN.md 'Kernels'): what the kernel must read +
+    write.  fft1 = kh_fft_cols reading the raw ring itself (8 B/sample cf32, N samples per block window) and writing the
     column-transformed block; chan = kh_back_a: per (channel, block) N_dec spectrum bins + N_dec response + the FM work
     record per output sample, plus compute_n0's second iteration (8 B per counted bin) when it rides along."""
     return {
@@ -79,9 +121,162 @@ def stage_bytes(bincount, n0_rides):
     }
 
 
-def cpu_baseline(x_host, rots, budget_s=12.0):
-    """the oracle (kind 'port': the CPU restatement, reference COPTS) on the same workload, single thread, bounded
-    sample.  TEST INFRASTRUCTURE used as a reported baseline only."""
+def time_steps(bank, step, steps, warm=5):
+    for _ in range(warm):
+        step()
+    bank.sync()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    bank.sync()
+    return (time.perf_counter() - t0) / steps
+
+
+def measure_shape(pyka9q, torch, device, shape, plan, nblocks, label, steps=40):
+    """one of the other BASELINE configurations on this GPU: step time (as the headline: raw input resident, launches
+    back to back), per-stage HIP-event times, SURVEY.md 8(d) bytes and what fraction of the HBM roofline they are"""
+    P = shape.P
+    if P == 1:
+        x = make_wideband_torch(shape, plan, nblocks * shape.L, device)
+    else:
+        x = make_pipelines_torch(shape, plan, nblocks * shape.L, device)
+    torch.cuda.synchronize()
+    bank = build_bank(pyka9q, shape, plan, nblocks)
+    if P == 1:
+        bank.write_input_device(0, x.data_ptr(), nblocks * shape.L)
+    else:
+        for i, ch in enumerate(plan):
+            bank.write_input_device(i, x[i].data_ptr(), nblocks * shape.L)
+            bank.set_lo(i, ch["lo2"], ch["doppler"], ch["doppler_rate"])
+
+    def step():
+        for i in range(P):
+            bank.commit_input(i, nblocks * shape.L)
+        bank.execute(nblocks, sync=False)
+
+    dt = time_steps(bank, step, steps)
+    bank.profile(1)
+    for _ in range(5):
+        step()
+    bank.sync()
+    st = bank.stage_times()
+    bank.profile(0)
+    bank.close()
+    del x
+    torch.cuda.empty_cache()
+    alg = shape.algorithmic_bytes(plan, nblocks)
+    kinds = {}
+    for ch in plan:
+        kinds[ch["kind"]] = kinds.get(ch["kind"], 0) + 1
+    return {"workload": label, "channels": len(plan), "kinds": kinds, "inputs": P, "N": shape.N, "blocks_per_step": nblocks,
+            "us_per_step": round(dt * 1e6, 1), "MSps": round(P * nblocks * shape.L / dt / 1e6, 1),
+            "realtime_factor": round((nblocks * shape.L / shape.fs) / dt, 1),
+            "algorithmic_bytes_per_step": alg, "algorithmic_GBps": round(alg / dt / 1e9, 1),
+            "frac_of_hbm_peak": round(alg / dt / 1e9 / HBM_PEAK_GBPS, 4),
+            "stage_us_hip_events": {k: round(1e3 * ms / n, 1) for k, (ms, n) in st.items() if n}}
+
+
+def shapes_leg(pyka9q, torch, device):
+    out = []
+    jobs = [
+        (workloads.CONFIG4, workloads.shard_plan(workloads.config4_plan(), workloads.CONFIG4, 8, 3)[0], 16,
+         "config 4, one GPU's share of 8: 64 MS/s cf32, N = 2^20, D = 2048, 512 of 4096 NBFM channels (contiguous in frequency)"),
+        (workloads.CONFIG3, workloads.shard_plan(workloads.config3_plan(), workloads.CONFIG3, 4, 1)[0], 32,
+         "config 3, one GPU's share of 4: 20 MS/s cf32, N = 2^19, D = 512, 256 of 1024 channels (NBFM / envelope AM / USB with hang AGC)"),
+        (workloads.CONFIG5, workloads.config5_plan(), 32,
+         "config 5: 256 independent pipelines at 192 kS/s (N = 8192, D = 4), Doppler NCO -> LO2 NCO -> filter -> linear demodulator with PLL + AGC"),
+    ]
+    for shape, plan, nb, label in jobs:
+        try:
+            out.append(measure_shape(pyka9q, torch, device, shape, plan, nb, label, steps=10 if shape.P > 1 else 40))
+        except Exception as e:  # an extra leg must never cost the bench line
+            out.append({"workload": label, "error": repr(e)})
+    return out
+
+
+def realtime_leg(pyka9q, torch, device, blocks=1000):
+    """BASELINE metric (i) on configs[1]'s stream: every 12.5 kHz channel the 8 MS/s band holds (640), block by block in
+    real time.  The producer writes s16le I/Q (IQ_PT, radio.c:159-167) into the library's pinned ring, kh_bank_stream_submit
+    moves it with hipMemcpyAsync on the copy stream and runs the launch behind it; the PCM of all channels is read back
+    after every block.  `late_blocks` counts blocks whose PCM was not back before the next block was due (a backlog)."""
+    shape = workloads.CONFIG2
+    plan = workloads.config2_plan(640)
+    Tr = 4
+    nsrc = 16  # distinct blocks of input, cycled
+    x = make_wideband_torch(shape, plan, nsrc * shape.L, device)
+    raw = torch.clamp(torch.round(x * (32767.0 * 4.0)), -32768, 32767).to(torch.int16).cpu().numpy().reshape(nsrc, 2 * shape.L)
+    del x
+    bank = build_bank(pyka9q, shape, plan, Tr, payload=pyka9q.KH_PT_IQ16LE)
+    bank.stream_open(4)
+    res = {"workload": "configs[1] stream, s16le wire format (IQ_PT), all 640 raster channels, pinned host ring -> hipMemcpyAsync "
+                       "on a copy stream -> launch; PCM of every channel read back",
+           "channels": len(plan), "block_ms": round(1e3 * shape.L / shape.fs, 3)}
+    # (a) unpaced, Tr blocks per submit: the PCIe-inclusive rate.  The producer's write into the pinned slot is included.
+    def unpaced(fill):
+        nsub = blocks // Tr
+        for j in range(8):
+            s = bank.stream_slot(0, np.int16, Tr * 2 * shape.L)
+            bank.stream_submit(Tr)
+        bank.sync()
+        t0 = time.perf_counter()
+        for j in range(nsub):
+            s = bank.stream_slot(0, np.int16, Tr * 2 * shape.L)
+            if fill:
+                for b in range(Tr):
+                    s[b * 2 * shape.L:(b + 1) * 2 * shape.L] = raw[(j * Tr + b) % nsrc]
+            bank.stream_submit(Tr)
+        bank.sync()
+        return (time.perf_counter() - t0) / (nsub * Tr)
+    s = None
+    for k in range(4):  # the four ring slots hold distinct data before the "ring pre-filled" pass
+        s = bank.stream_slot(0, np.int16, Tr * 2 * shape.L)
+        for b in range(Tr):
+            s[b * 2 * shape.L:(b + 1) * 2 * shape.L] = raw[(k * Tr + b) % nsrc]
+        bank.stream_submit(Tr)
+    bank.sync()
+    tb = unpaced(False)
+    res["pcie_inclusive"] = {"blocks_per_submit": Tr, "us_per_block": round(tb * 1e6, 2), "MSps": round(shape.L / tb / 1e6, 1),
+                             "H2D_GBps": round(4 * shape.L / tb / 1e9, 2), "realtime_factor": round((shape.L / shape.fs) / tb, 1),
+                             "note": "every submit crosses PCIe (pinned ring -> device raw ring); the producer's own write into the ring is not included"}
+    tf = unpaced(True)
+    res["pcie_inclusive_with_producer_copy"] = {"us_per_block": round(tf * 1e6, 2), "MSps": round(shape.L / tf / 1e6, 1),
+                                                "note": "as above plus a single-threaded numpy copy of every block into the pinned slot"}
+    res["extrapolated_channels_at_realtime"] = int(len(plan) * (shape.L / shape.fs) / tb)
+    # (b) paced: one block per submit, released at k * L / fs
+    pcm = np.empty((len(plan), shape.olen), np.int16)
+    period = shape.L / shape.fs
+    lat, late = [], 0
+    t0 = time.perf_counter() + 0.01
+    for k in range(blocks):
+        due = t0 + k * period
+        while True:
+            now = time.perf_counter()
+            if now >= due:
+                break
+            time.sleep(min(due - now, 0.002))
+        s = bank.stream_slot(0, np.int16, 2 * shape.L)
+        s[:] = raw[k % nsrc]
+        bank.stream_submit(1)
+        bank.pcm_all(1, pcm)
+        done = time.perf_counter()
+        lat.append(done - due)
+        if done > due + period:
+            late += 1
+    lat = np.array(lat)
+    res["paced"] = {"blocks": blocks, "blocks_per_submit": 1, "late_blocks": int(late), "holds_realtime": bool(late == 0),
+                    "latency_ms_release_to_pcm": {"mean": round(1e3 * float(lat.mean()), 3), "p99": round(1e3 * float(np.percentile(lat, 99)), 3),
+                                                  "max": round(1e3 * float(lat.max()), 3)},
+                    "busy_fraction": round(float(lat.mean()) / period, 4)}
+    res["channels_sustained_in_real_time"] = len(plan) if late == 0 else None
+    bank.stream_close()
+    bank.close()
+    return res
+
+
+def cpu_baseline(x_host, rots, budget_s=10.0):
+    """the oracle (kind 'port': the CPU restatement, the reference's COPTS) on the headline workload, bounded sample:
+    one thread, and the box's cores with the channels partitioned over threads behind one shared forward FFT per block
+    (SURVEY.md 8(d) CPU baseline plan).  TEST INFRASTRUCTURE used as a reported baseline only."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import pipeline
 
@@ -100,13 +295,28 @@ def cpu_baseline(x_host, rots, budget_s=12.0):
                 break
         return nb, time.perf_counter() - t0
 
-    # One thread.  (pipeline.Pipeline(threads=n) partitions the channels over n threads behind one shared forward FFT, as
-    # SURVEY.md 8(d) sketches; it gains under 10 % here because the port's forward transform, mix and compute_n0 are
-    # four fifths of a block and run on one thread -- so the single-thread figure is the one reported.)
+    try:
+        cores = min(16, len(os.sched_getaffinity(0)))  # the box's CPU share for one GPU
+    except AttributeError:
+        cores = min(16, os.cpu_count() or 1)
+    model = "unknown"
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                model = line.split(":", 1)[1].strip()
+                break
+    except OSError:
+        pass
     nb1, dt1 = run(1, budget_s)
-    return {"value": nb1 * L / dt1 / 1e6, "unit": "MS/s", "cores": 1, "kind": "port",
+    nbn, dtn = run(cores, budget_s)
+    return {"value": round(nb1 * L / dt1 / 1e6, 3), "unit": "MS/s", "cores": 1, "kind": "port",
             "sample": f"{nb1} blocks of {L} samples, {C} NBFM channels, {dt1:.1f} s of CPU time",
-            "ms_per_block": 1e3 * dt1 / nb1}
+            "ms_per_block": round(1e3 * dt1 / nb1, 3),
+            "all_cores": {"value": round(nbn * L / dtn / 1e6, 3), "unit": "MS/s", "cores": cores,
+                          "sample": f"{nbn} blocks, channels partitioned over {cores} threads, one shared forward FFT per block, {dtn:.1f} s",
+                          "ms_per_block": round(1e3 * dtn / nbn, 3)},
+            "cpu_model": model, "nproc_machine": os.cpu_count(),
+            "compiler": "gcc -O3 -DNDEBUG=1 -funsafe-math-optimizations (the reference's COPTS, Makefile:2, without -march=native); own radix-2/3/5/7 FFT, no FFTW"}
 
 
 def main():
@@ -115,6 +325,7 @@ def main():
     ap.add_argument("--steps", type=int, default=1000)
     ap.add_argument("--warmup", type=int, default=100)
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
+    ap.add_argument("--no-extra", action="store_true", help="skip the shapes and realtime legs")
     ap.add_argument("--blocks", type=int, default=T, help="blocks per step (per kh_bank_execute call)")
     ap.add_argument("--demod", default="fm", choices=["fm", "none"], help="diagnostic: 'none' runs the filter bank without demodulators")
     args = ap.parse_args()
@@ -146,16 +357,20 @@ def main():
     import pyka9q
     assert pyka9q.lib().ka9q_hip_init(local_rank) == 0, pyka9q.last_error()
 
-    plan, rots = channel_plan(rank)
-    x = make_input_torch(plan, device)
+    # 64 channels per GPU on the 12.5 kHz raster: the job's 64*world channels, sharded contiguously in frequency
+    full_plan = workloads.config2_plan(C * world)
+    plan, owned = workloads.shard_plan(full_plan, SH, world, rank)
+    assert len(plan) == C
+    rots = [ch["rotate"] for ch in plan]
+    x = make_wideband_torch(SH, plan, T * L, device)
     torch.cuda.synchronize()
 
     bank = pyka9q.Bank(L, M, D, 1, C, T, FS, payload=pyka9q.KH_PT_CF32, compute_n0=1, n0_low=-5500.0, n0_high=5500.0)
     bank.keep_audio(0)
     bank.keep_baseband(0)  # FM: filter output -> discriminator inside one kernel; PCM + status are the outputs
-    for c, r in enumerate(rots):
-        bank.set_channel(c, demod=pyka9q.KH_DEMOD_FM if args.demod == "fm" else pyka9q.KH_DEMOD_NONE, rotate=r,
-                         low=-5500.0, high=5500.0, kaiser_beta=3.0)
+    for c, ch in enumerate(plan):
+        bank.set_channel(c, demod=pyka9q.KH_DEMOD_FM if args.demod == "fm" else pyka9q.KH_DEMOD_NONE,
+                         **workloads.channel_kwargs(ch))
     bank.write_input_device(0, x.data_ptr(), T * L)  # device -> device; the ring now holds the step's samples
 
     def step():
@@ -230,12 +445,18 @@ def main():
     stat = bank.status(C - 1, T)
     pcm = bank.pcm(C - 1, T)
     assert args.demod != "fm" or (stat["squelch_open"].max() > 0 and np.abs(pcm).max() > 100), "bench produced no audio"
+    x_cpu = None
+    if rank == 0 and not args.no_cpu:
+        x_cpu = x[:6 * L].cpu().numpy().view(np.complex64).reshape(-1)
+    bank.close()
+    del x
+    torch.cuda.empty_cache()
 
     if rank == 0:
         bincount = N - (int((N * 5500.0) / FS) - int((N * -5500.0) / FS))
         # compute_n0's second iteration shares kh_back_a's launch for this shape (kh_bank.cpp enqueue_back)
         n0_rides = (ND == 1024 and 2 * OLEN == ND and os.environ.get("KA9Q_HIP_RIDE_N0", "1") != "0"
-                    and os.environ.get("KA9Q_HIP_CHAN_WAVE", "1") != "0")
+                    and os.environ.get("KA9Q_HIP_CHAN_WAVE", "1") != "0" and os.environ.get("KA9Q_HIP_N0_DIRECT", "-1") != "1")
         sb = stage_bytes(bincount, n0_rides)
         stages = {}
         # stages whose work rides in another kernel still record an (empty) event pair of ~5 us: no rate for those
@@ -251,19 +472,22 @@ def main():
                 else:
                     stages[name] = {"ms": round(avg, 5), "GBps": round(sb[name] / (avg * 1e-3) / 1e9, 1) if avg > 0 else None}
         dom = max((k for k in stages if k != "carry" and k not in empty), key=lambda k: stages[k]["ms"])
-        traffic = None  # HBM bytes per launch of that kernel from the committed PMC passes (profiles/, tools/summarize_prof.py)
+        traffic = traffic_src = None  # HBM bytes per launch of that kernel from the committed PMC passes (profiles/, tools/summarize_prof.py)
         try:
-            prof = json.load(open(os.path.join(ROOT, "profiles", "r01_step8_hbm_traffic.json")))["kernels"]
+            cands = sorted(glob.glob(os.path.join(ROOT, "profiles", "r0[2-9]_*hbm_traffic.json"))) or \
+                sorted(glob.glob(os.path.join(ROOT, "profiles", "r01_step8_hbm_traffic.json")))
+            prof = json.load(open(cands[-1]))["kernels"]
             key = {"fft1": "kh_fft_cols", "fft2": "kh_fft_rows", "chan": "kh_back_a", "demod": "kh_fm_finish_w", "n0": "kh_n0_pass1"}.get(dom)
             hit = [v for k, v in prof.items() if key and key in k]
             if hit and world == 1 and T == 32:
                 traffic = hit[0]["hbm_bytes_per_launch"]
-        except (OSError, ValueError, KeyError):
+                traffic_src = os.path.relpath(cands[-1], ROOT) + " (separate rocprofv3 --pmc passes of this command)"
+        except (OSError, ValueError, KeyError, IndexError):
             pass
         dom_ms = stages[dom]["ms"]
         achieved = sb[dom] / (dom_ms * 1e-3) / 1e9
         kernel_name = pyka9q.lib().kh_stage_kernel_name(pyka9q.KH_STAGES.index(dom)).decode()
-        total_alg = T * (16 * N + C * (16 * ND + 2 * OLEN))  # BASELINE.md section 3 formula
+        total_alg = SH.algorithmic_bytes(plan, T)  # BASELINE.md section 3 formula
         ms_per_step = 1e3 * dt / args.steps
         out = {
             "metric": "aggregate MS/s (input samples consumed per second, all GPUs) on 8 MS/s wideband, 64 NBFM channels per GPU",
@@ -281,14 +505,17 @@ def main():
             "data": "synthetic" if not rehearse else "synthetic (REHEARSAL: all ranks on one GPU, gloo; not a measurement)",
             "config": {"workload": "configs[1]: 8 MS/s cf32 wideband, L=131072 M=131073 N=262144, D=256 -> 31.25 kS/s, "
                                    "64 NBFM 12.5 kHz channels per GPU, 32 blocks (4.19 MS, 0.524 s of signal) per step",
-                       "blocks_per_step": T, "channels_per_gpu": C, "sharding": "channels disjoint per GPU, FFT recomputed per GPU"},
+                       "blocks_per_step": T, "channels_per_gpu": C,
+                       "sharding": "ka9q-radio_amd/shard.py: channels disjoint and contiguous in frequency per GPU, FFT recomputed per GPU",
+                       "rank0_channels_k": [int(plan[0]["k"]), int(plan[-1]["k"])]},
             "channel_MS_per_s": round(world * C * args.steps * T * L / dt / 1e6, 1),
             "realtime_factor": round((T * L / FS) / (dt / args.steps), 1),
             "pipeline_GBps_algorithmic": round(total_alg / (ms_per_step * 1e-3) / 1e9, 1),
+            "pipeline_frac_of_hbm_peak": round(total_alg / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
             "stages": stages,
             "roofline": {"bound": "hbm", "kernel": kernel_name, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS,
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic,
-                         "traffic_source": "profiles/r01_step8_hbm_traffic.json (separate rocprofv3 --pmc passes of this command)" if traffic else None,
+                         "traffic_source": traffic_src,
                          "algorithmic_bytes_per_launch": sb[dom], "avg_launch_ms": dom_ms},
         }
         if probe is not None:
@@ -297,11 +524,15 @@ def main():
             if "broadcast_spectrum_ms" in probe:
                 probe["cheaper"] = "recompute per GPU" if fft_ms <= probe["broadcast_spectrum_ms"] else "spectrum broadcast"
             out["exchange_probe"] = probe
-        if not args.no_cpu:
-            nb = 6
-            out["cpu_baseline"] = cpu_baseline(x[:nb * L].cpu().numpy().view(np.complex64).reshape(-1), rots)
+        if world == 1 and not args.no_extra:
+            out["shapes"] = shapes_leg(pyka9q, torch, device)
+            try:
+                out["realtime"] = realtime_leg(pyka9q, torch, device)
+            except Exception as e:
+                out["realtime"] = {"error": repr(e)}
+        if x_cpu is not None:
+            out["cpu_baseline"] = cpu_baseline(x_cpu, rots)
         print(json.dumps(out), flush=True)
-    bank.close()
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

@@ -403,6 +403,8 @@ int kh_hackrf_pack(int payload, const float *ip, const float *qp, unsigned int c
 int kh_hackrf_pack_noalloc(int payload, const float *ip, const float *qp, unsigned int chunk, float filter_atten, void *out,
                            float *output_energy, void *stream);
 
+/* diagnostic: one character per stream / event of the bank ('.' idle or complete, 'P' pending, 'E' error) */
+int kh_bank_debug_pending(kh_bank *, char *buf, size_t n);
 void *kh_bank_stream(kh_bank *); /* hipStream_t */
 /* per-kernel timing with HIP events on the bank's stream.  Stages: */
 enum kh_stage { KH_STAGE_INGEST = 0, KH_STAGE_FFT1, KH_STAGE_FFT2, KH_STAGE_N0, KH_STAGE_CHAN, KH_STAGE_DEMOD,

@@ -14,6 +14,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <algorithm>
+#include <string>
 #include <vector>
 
 #include "../../include/ka9q_hip.h"
@@ -114,6 +115,7 @@ struct kh_bank {
   std::vector<size_t> fill; // samples present in each input's raw ring
   std::vector<int> lists;
   int n_fm = 0, n_lin = 0, n_am = 0;
+  int n_lin_nopll = 0; // the linear list holds the channels without PLL first
   bool chans_dirty = true;
   unsigned last_blocks = 0;
   int keep_audio = 1, keep_baseband = 1;
@@ -134,17 +136,19 @@ struct kh_bank {
   // launches, so graphs are off unless asked for
   int use_graph = 0;
   // streaming ingest (kh_bank_stream_*): a pinned host ring of `stream_depth` slots per input, fed to two device raw
-  // rings by hipMemcpyAsync on a copy stream of its own, so that the transfer of launch k+1 runs beside launch k
-  unsigned char *h_ring = nullptr;
+  // rings by a transfer kernel (kh_host_pull) on a copy stream of its own, so that the transfer of launch k+1 runs beside launch k
+  int16_t *h_pcm = nullptr;       // pinned staging of kh_bank_read_pcm_all (C x pcm_stride words), allocated on first use
+  unsigned char *h_ring = nullptr, *h_ring_dev = nullptr; // the pinned ring and its address as the device sees it
   size_t h_slot_bytes = 0;        // bytes of one input's slot (max_blocks*L samples of the wire format)
   unsigned stream_depth = 0;
   unsigned long long stream_k = 0; // submits so far
   hipStream_t copy = nullptr;
-  std::vector<hipEvent_t> ev_h2d;  // per host slot: the copy out of it has completed
-  std::vector<char> ev_h2d_rec;
+  int stream_sdma = 0, stream_hostwait = 0; // KA9Q_HIP_STREAM_SDMA, KA9Q_HIP_STREAM_HOSTWAIT as read by kh_bank_stream_open
+  // Events of submit k live at index k % (depth + 2): an event is recorded again only after every wait that was queued
+  // on its earlier record has been passed.
+  std::vector<hipEvent_t> ev_h2d;      // the transfer of submit k has completed
+  std::vector<hipEvent_t> ev_raw_free; // the front half of submit k has read its device ring
   unsigned char *d_raw_buf[2] = {nullptr, nullptr}; // [0] is d_raw as created
-  hipEvent_t ev_raw_free[2] = {};  // the front half that read this device ring has run
-  bool raw_free_rec[2] = {false, false};
   // profiling
   bool profiling = false;
   hipEvent_t ev[KH_STAGE_COUNT + 2] = {};
@@ -188,6 +192,7 @@ int kh_bank_destroy(kh_bank *b) {
   for (auto &e : b->idesc_ev)
     if (e) hipEventDestroy(e);
   if (b->h_idesc) hipHostFree(b->h_idesc);
+  if (b->h_pcm) hipHostFree(b->h_pcm);
   for (auto &e : b->ev_front_done)
     if (e) hipEventDestroy(e);
   for (auto &e : b->ev_back_done)
@@ -521,16 +526,28 @@ int kh_bank_stream_open(kh_bank *b, unsigned int depth) {
   }
   size_t const P = b->P;
   b->h_slot_bytes = b->raw_stride;
-  bool ok = KH_HIP(hipHostMalloc((void **)&b->h_ring, (size_t)depth * P * b->h_slot_bytes, hipHostMallocDefault));
-  ok = ok && KH_HIP(hipStreamCreateWithFlags(&b->copy, hipStreamNonBlocking));
+  bool ok = KH_HIP(hipHostMalloc((void **)&b->h_ring, (size_t)depth * P * b->h_slot_bytes, hipHostMallocMapped));
+  // (the staging of kh_bank_read_pcm_all as well: nothing is allocated once samples flow)
+  if (ok && !b->h_pcm) ok = KH_HIP(hipHostMalloc((void **)&b->h_pcm, (size_t)b->C * b->pcm_stride * sizeof(int16_t), hipHostMallocDefault));
+  ok = ok && KH_HIP(hipHostGetDevicePointer((void **)&b->h_ring_dev, b->h_ring, 0));
+  {
+    // at the highest priority: the runtime keeps the hardware queues of each priority apart, so the transfers do not
+    // share a queue with the compute streams whose launches wait for them (see kh_bank_stream_submit)
+    int least = 0, greatest = 0;
+    ok = ok && KH_HIP(hipDeviceGetStreamPriorityRange(&least, &greatest));
+    int const prio = getenv("KA9Q_HIP_STREAM_PRIO") ? atoi(getenv("KA9Q_HIP_STREAM_PRIO")) : 1;
+    b->stream_sdma = getenv("KA9Q_HIP_STREAM_SDMA") ? atoi(getenv("KA9Q_HIP_STREAM_SDMA")) : 1;
+    b->stream_hostwait = getenv("KA9Q_HIP_STREAM_HOSTWAIT") ? atoi(getenv("KA9Q_HIP_STREAM_HOSTWAIT")) : 0;
+    ok = ok && (prio ? KH_HIP(hipStreamCreateWithPriority(&b->copy, hipStreamNonBlocking, greatest))
+                     : KH_HIP(hipStreamCreateWithFlags(&b->copy, hipStreamNonBlocking)));
+  }
   b->d_raw_buf[0] = b->d_raw;
   ok = ok && KH_HIP(hipMalloc((void **)&b->d_raw_buf[1], P * b->raw_stride));
   ok = ok && KH_HIP(hipMemset(b->d_raw_buf[1], 0, P * b->raw_stride));
-  b->ev_h2d.assign(depth, nullptr);
-  b->ev_h2d_rec.assign(depth, 0);
+  b->ev_h2d.assign(depth + 2, nullptr);
+  b->ev_raw_free.assign(depth + 2, nullptr);
   for (auto &e : b->ev_h2d) ok = ok && KH_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
   for (auto &e : b->ev_raw_free) ok = ok && KH_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-  b->raw_free_rec[0] = b->raw_free_rec[1] = false;
   b->stream_k = 0;
   b->stream_depth = depth;
   if (!ok) {
@@ -547,15 +564,14 @@ int kh_bank_stream_close(kh_bank *b) {
   for (auto &e : b->ev_h2d)
     if (e) hipEventDestroy(e);
   b->ev_h2d.clear();
-  for (auto &e : b->ev_raw_free) {
+  for (auto &e : b->ev_raw_free)
     if (e) hipEventDestroy(e);
-    e = nullptr;
-  }
+  b->ev_raw_free.clear();
   if (b->d_raw_buf[0]) b->d_raw = b->d_raw_buf[0]; // what kh_bank_destroy frees
   if (b->d_raw_buf[1]) hipFree(b->d_raw_buf[1]);
   b->d_raw_buf[0] = b->d_raw_buf[1] = nullptr;
   if (b->h_ring) hipHostFree(b->h_ring);
-  b->h_ring = nullptr;
+  b->h_ring = b->h_ring_dev = nullptr;
   if (b->copy) hipStreamDestroy(b->copy);
   b->copy = nullptr;
   b->stream_depth = 0;
@@ -567,8 +583,9 @@ void *kh_bank_stream_slot(kh_bank *b, unsigned int input, size_t *capacity_sampl
     return nullptr;
   }
   unsigned const slot = (unsigned)(b->stream_k % b->stream_depth);
+  size_t const R = b->ev_h2d.size();
   // the transfer that last left this slot (depth submits ago) must have completed before the producer overwrites it
-  if (b->ev_h2d_rec[slot] && !KH_HIP(hipEventSynchronize(b->ev_h2d[slot]))) return nullptr;
+  if (b->stream_k >= b->stream_depth && !KH_HIP(hipEventSynchronize(b->ev_h2d[(b->stream_k - b->stream_depth) % R]))) return nullptr;
   if (capacity_samples) *capacity_samples = (size_t)b->T * b->cfg.L;
   return b->h_ring + ((size_t)slot * b->P + input) * b->h_slot_bytes;
 }
@@ -581,37 +598,73 @@ int kh_bank_stream_submit(kh_bank *b, unsigned int nblocks) {
     set_error("kh_bank_stream_submit: nblocks %u outside [1, %d]", nblocks, b->T);
     return -1;
   }
-  unsigned const slot = (unsigned)(b->stream_k % b->stream_depth);
-  int const dev = (int)(b->stream_k & 1);
+  unsigned long long const k = b->stream_k;
+  unsigned const slot = (unsigned)(k % b->stream_depth);
+  size_t const R = b->ev_h2d.size(), e = k % R;
+  int const dev = (int)(k & 1);
   size_t const bytes = payload_bytes(b->cfg.payload, (size_t)nblocks * b->cfg.L);
-  // the front half that last read this device ring (two submits ago) runs before the copy overwrites it
-  if (b->raw_free_rec[dev] && !KH_HIP(hipStreamWaitEvent(b->copy, b->ev_raw_free[dev], 0))) return -1;
-  for (int i = 0; i < b->P; i++)
-    if (!KH_HIP(hipMemcpyAsync(b->d_raw_buf[dev] + (size_t)i * b->raw_stride,
-                               b->h_ring + ((size_t)slot * b->P + i) * b->h_slot_bytes, bytes, hipMemcpyHostToDevice, b->copy)))
-      return -1;
-  if (!KH_HIP(hipEventRecord(b->ev_h2d[slot], b->copy))) return -1;
-  b->ev_h2d_rec[slot] = 1;
-  // whichever stream the front half takes (profiling passes put it on the back stream) waits for the samples
-  if (!KH_HIP(hipStreamWaitEvent(b->front, b->ev_h2d[slot], 0)) || !KH_HIP(hipStreamWaitEvent(b->stream, b->ev_h2d[slot], 0)))
+  // The front half that last read this device ring (two submits ago) must have run before the transfer overwrites it.
+  // Waited for on the HOST: that front half started when the transfer before last ended, so it is normally over, and
+  // the transfer of submit k-1 keeps the link busy meanwhile; a producer that runs ahead of the GPU is held here.
+  if (k >= 2 && !KH_HIP(hipEventSynchronize(b->ev_raw_free[(k - 2) % R]))) return -1;
+  if (b->stream_sdma) { // the copy engines (measured 34 GB/s against the transfer kernel's 28 GB/s; KA9Q_HIP_STREAM_SDMA=0 takes the kernel)
+    for (int i = 0; i < b->P; i++)
+      if (!KH_HIP(hipMemcpyAsync(b->d_raw_buf[dev] + (size_t)i * b->raw_stride, b->h_ring + ((size_t)slot * b->P + i) * b->h_slot_bytes,
+                                 bytes, hipMemcpyHostToDevice, b->copy)))
+        return -1;
+  } else if (launch_host_pull(b->copy, b->h_ring_dev + (size_t)slot * b->P * b->h_slot_bytes, b->d_raw_buf[dev], b->raw_stride, bytes,
+                              b->P))
     return -1;
+  if (!KH_HIP(hipEventRecord(b->ev_h2d[e], b->copy))) return -1;
+  // the stream the front half takes (profiling passes and one-stream mode put it on the back stream) waits for the samples
+  hipStream_t const fs = (b->profiling || !b->pipeline) ? b->stream : b->front;
+  // (KA9Q_HIP_STREAM_HOSTWAIT=1: the host waits for the transfer instead, and no stream waits for another)
+  if (b->stream_hostwait ? !KH_HIP(hipEventSynchronize(b->ev_h2d[e])) : !KH_HIP(hipStreamWaitEvent(fs, b->ev_h2d[e], 0))) return -1;
   b->d_raw = b->d_raw_buf[dev];
   for (int i = 0; i < b->P; i++) b->fill[i] = (size_t)nblocks * b->cfg.L;
   int const rc = kh_bank_execute(b, nblocks);
   if (rc) return rc;
-  hipStream_t const fs = (b->profiling || !b->pipeline) ? b->stream : b->front;
-  if (!KH_HIP(hipEventRecord(b->ev_raw_free[dev], fs))) return -1;
-  b->raw_free_rec[dev] = true;
+  if (!KH_HIP(hipEventRecord(b->ev_raw_free[e], fs))) return -1;
   b->stream_k++;
+  return 0;
+}
+// diagnostic: which of the bank's streams and events still have work outstanding, as text
+int kh_bank_debug_pending(kh_bank *b, char *buf, size_t n) {
+  if (!b || !buf || n == 0) return -1;
+  auto q = [](hipError_t e) { (void)hipGetLastError(); return e == hipSuccess ? '.' : e == hipErrorNotReady ? 'P' : 'E'; };
+  std::string o = "streams back/front/copy: ";
+  o += q(hipStreamQuery(b->stream));
+  o += q(hipStreamQuery(b->front));
+  o += b->copy ? q(hipStreamQuery(b->copy)) : '-';
+  o += " front_done: ";
+  for (auto &e : b->ev_front_done) o += q(hipEventQuery(e));
+  o += " back_done: ";
+  for (auto &e : b->ev_back_done) o += q(hipEventQuery(e));
+  o += " h2d: ";
+  for (auto &e : b->ev_h2d) o += q(hipEventQuery(e));
+  o += " raw_free: ";
+  for (auto &e : b->ev_raw_free) o += q(hipEventQuery(e));
+  snprintf(buf, n, "%s", o.c_str());
   return 0;
 }
 // PCM of every channel of the last launch in one transfer: out[ch*nwords .. ] (host memory); synchronises
 int kh_bank_read_pcm_all(kh_bank *b, int16_t *out, size_t nwords) {
   if (!b || !out || nwords > b->pcm_stride) return -1;
-  if (!KH_HIP(hipMemcpy2DAsync(out, nwords * sizeof(int16_t), b->d_pcm, b->pcm_stride * sizeof(int16_t), nwords * sizeof(int16_t),
-                               b->C, hipMemcpyDeviceToHost, b->stream)))
+  // through pinned memory: a strided copy into pageable memory goes row by row (measured: 4.4 ms for 640 rows of 1 KiB)
+  if (!b->h_pcm) { // first use on a bank without a stream (kh_bank_stream_open allocates it): with the queues drained
+    if (kh_bank_sync(b)) return -1;
+    if (!KH_HIP(hipHostMalloc((void **)&b->h_pcm, (size_t)b->C * b->pcm_stride * sizeof(int16_t), hipHostMallocDefault))) return -1;
+  }
+  // the launches first, then the copy: a strided device-to-host copy queued behind launches that themselves wait for
+  // host-to-device transfers of the streaming ring did not return on ROCm 7.2 (three submits in flight; the copy
+  // engines' queues); with the stream drained the copy depends on nothing
+  if (!KH_HIP(hipStreamSynchronize(b->stream))) return -1;
+  if (!KH_HIP(hipMemcpy2DAsync(b->h_pcm, nwords * sizeof(int16_t), b->d_pcm, b->pcm_stride * sizeof(int16_t),
+                               nwords * sizeof(int16_t), b->C, hipMemcpyDeviceToHost, b->stream)))
     return -1;
-  return KH_HIP(hipStreamSynchronize(b->stream)) ? 0 : -1;
+  if (!KH_HIP(hipStreamSynchronize(b->stream))) return -1;
+  memcpy(out, b->h_pcm, (size_t)b->C * nwords * sizeof(int16_t));
+  return 0;
 }
 
 static int upload_channels(kh_bank *b) {
@@ -620,11 +673,16 @@ static int upload_channels(kh_bank *b) {
   for (int ch = 0; ch < C; ch++) {
     switch (b->ddesc[ch].demod) {
     case KH_DEMOD_FM: b->lists[b->n_fm++] = ch; break;
-    case KH_DEMOD_LINEAR: b->lists[C + b->n_lin++] = ch; break;
+    case KH_DEMOD_LINEAR:
+      if (!b->ddesc[ch].pll) b->lists[C + b->n_lin++] = ch;
+      break;
     case KH_DEMOD_AM: b->lists[2 * C + b->n_am++] = ch; break;
     default: break;
     }
   }
+  b->n_lin_nopll = b->n_lin;
+  for (int ch = 0; ch < C; ch++)
+    if (b->ddesc[ch].demod == KH_DEMOD_LINEAR && b->ddesc[ch].pll) b->lists[C + b->n_lin++] = ch;
   hipStream_t st = b->stream;
   bool ok = KH_HIP(hipMemcpyAsync(b->d_chans, b->chans.data(), C * sizeof(ChanDesc), hipMemcpyHostToDevice, st));
   ok = ok && KH_HIP(hipMemcpyAsync(b->d_ddesc, b->ddesc.data(), C * sizeof(DemodDesc), hipMemcpyHostToDevice, st));
@@ -730,7 +788,8 @@ static int enqueue_back(kh_bank *b, hipStream_t st, unsigned int nblocks, bool p
   if (launch_demod(st, b->d_bb, b->bb_stride, b->olen, nblocks, C, b->d_ddesc, b->d_dstate,
                    b->keep_audio ? b->d_audio : nullptr, b->d_pcm, b->pcm_stride, b->cfg.pcm_big_endian, b->d_status,
                    b->T, b->d_lists, b->n_fm, b->d_lists + C, b->n_lin, b->d_lists + 2 * C, b->n_am,
-                   FmScratch{b->d_fmstat, b->d_fmwork, b->d_fmcarry, b->d_decaypow, b->fm_parity}, ride_final ? &nf : nullptr))
+                   FmScratch{b->d_fmstat, b->d_fmwork, b->d_fmcarry, b->d_decaypow, b->fm_parity}, ride_final ? &nf : nullptr,
+                   b->n_lin_nopll))
     return -1;
   if (b->rtp && launch_rtp_plan(st, b->d_pcm, b->pcm_stride, b->olen, nblocks, C, b->d_ddesc, b->d_rtp, b->rtp_stride,
                                 b->d_rtpstate))

@@ -13,6 +13,7 @@
 // Mapping: work that is parallel inside a block (discriminator, statistics, PCM) runs one workgroup per
 // channel; the per-sample recurrences of linear.c / am.c (PLL, hang AGC, DC tracker) are serial by
 // definition and run one LANE per channel, 64 channels in lock-step per wavefront.
+#include <type_traits>
 #include "kh_internal.h"
 #include <cstdlib>
 #include "kh_fft.cuh"
@@ -959,6 +960,172 @@ __global__ __launch_bounds__(64) void kh_demod_linear(float2 *__restrict__ baseb
   states[ch] = s;
 }
 
+// ================================================================ linear without PLL: one wavefront per channel
+// linear.c:114-148 when opt.pll is off (SSB, IQ, ISB, envelope AM: every modes.txt entry except CAM / DSB-with-PLL).
+// Only the AGC (linear.c:127-136) chains from sample to sample, and it chains through three numbers: the sample's
+// amplitude, the gain and the hang counter.  So a block is three steps, all in registers (lane l holds samples
+// l, l + 64, ... of the block: K = ceil(olen / 64) of them):
+//   1  all lanes: post-detection shift (radio.c:355-361; the oscillator in closed form from the phase the state holds),
+//      |s|^2, amplitude, and headroom / amplitude (the gain an attack would set);
+//   2  the AGC state machine over the block's amplitudes, sample by sample, in the reference's order and precision:
+//      sample n's two numbers come out of lane n % 64 by v_readlane (a constant lane: the loop is unrolled), every lane
+//      runs the same few instructions on them, and a select leaves the sample's gain in the lane that owns it;
+//   3  all lanes: envelope / mono / stereo output x gain, scaleclip, coalesced stores, level sums.
+// The serial part is ~10 instructions per sample with no memory access, instead of the ~300 of kh_demod_linear's
+// per-sample loop.  algorithmic bytes per (channel, block): 8 olen read + (2 or 4) olen PCM (+ 8 olen baseband
+// rewritten for stereo, linear.c:145).
+template <int N, typename F>
+__device__ __forceinline__ void static_for(F &&f) { // f(integral_constant<int, 0>) ... f(integral_constant<int, N - 1>)
+  if constexpr (N > 0) {
+    static_for<N - 1>(f);
+    f(std::integral_constant<int, N - 1>{});
+  }
+}
+__device__ __forceinline__ float lane_value(float v, int l) { // v of lane l (a constant), to every lane
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l));
+}
+template <int K>
+__global__ __launch_bounds__(64) void kh_demod_linear_w(float2 *__restrict__ baseband, size_t bb_stride, int olen,
+                                                        int nblocks, const DemodDesc *__restrict__ descs,
+                                                        DemodState *__restrict__ states, float *__restrict__ audio,
+                                                        int16_t *__restrict__ pcm, size_t pcm_stride, int big_endian,
+                                                        kh_status *__restrict__ status, int status_stride,
+                                                        const int *__restrict__ list) {
+  int const lane = threadIdx.x;
+  int const ch = list[blockIdx.x];
+  DemodDesc const d = descs[ch];
+  DemodState s = states[ch];
+  float2 *y = baseband + (size_t)ch * bb_stride;
+  float *ao = audio ? audio + (size_t)ch * pcm_stride : nullptr;
+  int16_t *po = pcm + (size_t)ch * pcm_stride;
+  // the shift oscillator (osc.c:22-50): phasor = cis(2 pi (phase0 + f m)) at sample m of the launch
+  bool const shift_active = !(d.shift_freq == 0.0 && s.shift_re == 1.0 && s.shift_im == 0.0);
+  double const phase0 = shift_active ? atan2(s.shift_im, s.shift_re) * (0.5 / M_PI) : 0.0;
+  float gain = s.agc_gain;
+  int hang = s.hangcount;
+  int const H = (int)d.hangtime;
+  for (int b = 0; b < nblocks; b++) {
+    float2 *yb = y + (size_t)b * olen;
+    // ---- step 1
+    float2 sm[K];
+    float amp[K], gatt[K], gn[K];
+    float energy = 0.f;
+#pragma unroll
+    for (int j = 0; j < K; j++) {
+      int const n = lane + 64 * j;
+      float2 v = n < olen ? yb[n] : make_float2(1.f, 0.f);
+      if (shift_active) {
+        double sn, cs;
+        double ph = phase0 + d.shift_freq * (double)((size_t)b * olen + n);
+        ph -= rint(ph);
+        sincospi(2.0 * ph, &sn, &cs);
+        v = make_float2((float)((double)v.x * cs - (double)v.y * sn), (float)((double)v.x * sn + (double)v.y * cs));
+      }
+      sm[j] = v;
+      float const norm = v.x * v.x + v.y * v.y;
+      if (n < olen) energy += norm;
+      amp[j] = sqrtf(norm);
+      gatt[j] = d.headroom / amp[j];
+      gn[j] = gain;
+    }
+    // ---- step 2: linear.c:127-136
+    if (d.agc) {
+      auto agc_step = [&](float &gn_j, float amp_j, float gatt_j, auto lc) {
+        constexpr int l = decltype(lc)::value;
+        float const a = lane_value(amp_j, l), g = lane_value(gatt_j, l);
+        // Every lane computes the same numbers, but the compiler must not know: with provably uniform values it turns
+        // the state machine into scalar compares and a branch per sample, and every hop between the vector and the
+        // scalar side waits out a pipeline (measured: 115 cycles per sample).  As plain per-lane arithmetic it is five
+        // dependent vector instructions.
+        asm volatile("" : "+v"(gain), "+v"(hang));
+        float const t = isnan(gain) ? INFINITY : a * gain; // linear.c:127: isnan(gain) || amplitude * gain > headroom
+        bool const attack = t > d.headroom;
+        bool const hanging = hang > 0;
+        float const rec = gain * d.recovery_rate;
+        gain = attack ? g : (hanging ? gain : rec);
+        int const hm = hang - 1;
+        hang = attack ? H : (hm > 0 ? hm : 0);
+        // the sample's gain stays with the lane that owns the sample (a lane write: a select on `lane == l` would keep
+        // 64 loop-invariant lane masks alive in scalar registers)
+        int const sg = __builtin_amdgcn_readfirstlane(__float_as_int(gain));
+        asm volatile("v_writelane_b32 %0, %1, %2" : "+v"(gn_j) : "s"(sg), "n"(l));
+      };
+      int const full_rows = olen / 64, tail = olen % 64; // every shape in use has tail == 0
+      static_for<K>([&](auto jc) { // (static row index: a run-time one would turn gn[j] into a chain of selects)
+        constexpr int j = decltype(jc)::value;
+        if (j < full_rows) { // uniform
+          static_for<64>([&](auto lc) {
+            agc_step(gn[j], amp[j], gatt[j], lc);
+            // (the lane reads do not depend on the chain: left alone, the scheduler hoists all of them to the top)
+            if constexpr ((decltype(lc)::value & 7) == 7) __builtin_amdgcn_sched_barrier(0);
+          });
+        } else if (j == full_rows && tail) {
+          static_for<64>([&](auto lc) {
+            if (decltype(lc)::value < tail) agc_step(gn[j], amp[j], gatt[j], lc);
+          });
+        }
+      });
+    }
+    // ---- step 3: linear.c:137-148
+    float level = 0.f;
+#pragma unroll
+    for (int j = 0; j < K; j++) {
+      int const n = lane + 64 * j;
+      if (n >= olen) continue;
+      size_t const o = (size_t)b * olen + n;
+      if (d.env) {
+        float const smp = amp[j] * gn[j];
+        level += smp * smp;
+        if (ao) ao[o] = smp;
+        po[o] = pcm_word(smp, big_endian);
+      } else if (d.channels == 1) {
+        float const smp = sm[j].x * gn[j];
+        level += smp * smp;
+        if (ao) ao[o] = smp;
+        po[o] = pcm_word(smp, big_endian);
+      } else {
+        float2 const w = make_float2(sm[j].x * gn[j], sm[j].y * gn[j]);
+        yb[n] = w; // linear.c:145
+        level += w.x * w.x + w.y * w.y;
+        if (ao) reinterpret_cast<float2 *>(ao)[o] = w;
+        reinterpret_cast<short2 *>(po)[o] = make_short2(pcm_word(w.x, big_endian), pcm_word(w.y, big_endian));
+      }
+    }
+    energy = wave_sum(energy);
+    level = wave_sum(level);
+    if (lane == 0) {
+      kh_status r;
+      r.bb_power = energy / olen;
+      r.snr = s.snr;
+      r.foffset = 0.f;
+      r.pdeviation = 0.f;
+      r.cphase = 0.f;
+      r.lock_timer = 0.f;
+      r.pll_lock = s.pll_lock;
+      r.output_level = level / (olen * d.channels);
+      r.agc_gain = gain;
+      r.squelch_open = 0;
+      r.reserved[0] = r.reserved[1] = 0.f;
+      status[(size_t)ch * status_stride + b] = r;
+    }
+  }
+  if (lane == 0) {
+    size_t const total = (size_t)nblocks * olen;
+    if (shift_active) {
+      double sn, cs;
+      double ph = phase0 + d.shift_freq * (double)total;
+      ph -= rint(ph);
+      sincospi(2.0 * ph, &sn, &cs);
+      s.shift_re = cs;
+      s.shift_im = sn;
+    }
+    s.shift_steps = (int)((s.shift_steps + total) % 16384); // Renorm_rate, osc.c:11
+    s.agc_gain = gain;
+    s.hangcount = hang;
+    states[ch] = s;
+  }
+}
+
 // ================================================================ AM: am.c:42-91, one lane per channel
 __global__ __launch_bounds__(64) void kh_demod_am(const float2 *__restrict__ baseband, size_t bb_stride, int olen,
                                                   int nblocks, const DemodDesc *__restrict__ descs,
@@ -1090,7 +1257,7 @@ int launch_rtp_plan(hipStream_t st, const int16_t *pcm, size_t pcm_stride, int o
 int launch_demod(hipStream_t st, float2 *baseband, size_t bb_stride, int olen, int nblocks, int nchan,
                  const DemodDesc *desc, DemodState *state, float *audio, int16_t *pcm, size_t pcm_stride,
                  int pcm_big_endian, void *status, int status_stride, const int *fm_list, int n_fm, const int *lin_list,
-                 int n_lin, const int *am_list, int n_am, const FmScratch &fm, const N0FinalArgs *n0final) {
+                 int n_lin, const int *am_list, int n_am, const FmScratch &fm, const N0FinalArgs *n0final, int n_lin_nopll) {
   (void)nchan;
   if (nblocks <= 0) return 0;
   kh_status *stt = static_cast<kh_status *>(status);
@@ -1118,9 +1285,18 @@ int launch_demod(hipStream_t st, float2 *baseband, size_t bb_stride, int olen, i
     else
       hipLaunchKernelGGL(kh_fm_finish_w<16>, grid, dim3(256), 0, st, F, npairs, nfin, Z);
   }
-  if (n_lin > 0)
-    hipLaunchKernelGGL(kh_demod_linear, dim3((n_lin + 63) / 64), dim3(64), 0, st, baseband, bb_stride, olen, nblocks,
-                       desc, state, audio, pcm, pcm_stride, pcm_big_endian, stt, status_stride, lin_list, n_lin);
+  // the first n_lin_nopll entries of lin_list have opt.pll off: one wavefront each (kh_demod_linear_w); the others keep
+  // the lane-per-channel loop.  KA9Q_HIP_LINEAR_WAVE=0 sends every linear channel there (A/B switch).
+  static int const lin_wave_env = getenv("KA9Q_HIP_LINEAR_WAVE") ? atoi(getenv("KA9Q_HIP_LINEAR_WAVE")) : 1;
+  int const nw = (lin_wave_env && olen <= 1024) ? (n_lin_nopll < n_lin ? n_lin_nopll : n_lin) : 0;
+  if (nw > 0) {
+    auto const kern = olen <= 256 ? kh_demod_linear_w<4> : olen <= 512 ? kh_demod_linear_w<8> : kh_demod_linear_w<16>;
+    hipLaunchKernelGGL(kern, dim3(nw), dim3(64), 0, st, baseband, bb_stride, olen, nblocks, desc, state, audio, pcm, pcm_stride,
+                       pcm_big_endian, stt, status_stride, lin_list);
+  }
+  if (n_lin - nw > 0)
+    hipLaunchKernelGGL(kh_demod_linear, dim3((n_lin - nw + 63) / 64), dim3(64), 0, st, baseband, bb_stride, olen, nblocks,
+                       desc, state, audio, pcm, pcm_stride, pcm_big_endian, stt, status_stride, lin_list + nw, n_lin - nw);
   if (n_am > 0)
     hipLaunchKernelGGL(kh_demod_am, dim3((n_am + 63) / 64), dim3(64), 0, st, baseband, bb_stride, olen, nblocks, desc,
                        state, audio, pcm, pcm_stride, pcm_big_endian, stt, status_stride, am_list, n_am);

@@ -1128,6 +1128,38 @@ int launch_carry(hipStream_t st, const void *src, void *dst, size_t row_stride_b
   return KH_HIP(hipGetLastError()) ? 0 : -1;
 }
 
+// ================================================================ streaming ingest: pinned host ring -> device raw ring
+// The transfer of kh_bank_stream_submit as a kernel (KA9Q_HIP_STREAM_SDMA=0; the default is hipMemcpyAsync on the copy
+// engines, 34 GB/s against this kernel's 28 GB/s on the test box): the lanes read the pinned slot over PCIe (host memory
+// mapped into the device's address space) and write the device ring.  A few workgroups hold enough 16-byte reads in
+// flight to keep the link busy and leave the other CUs to the launch running beside it.
+// Rows start 16-byte aligned (raw_stride is a multiple of 256); algorithmic bytes: `bytes` read + `bytes` written per row.
+__global__ __launch_bounds__(256) void kh_host_pull(const unsigned char *__restrict__ src, unsigned char *__restrict__ dst,
+                                                    size_t row_stride, size_t bytes) {
+  const unsigned char *s = src + (size_t)blockIdx.y * row_stride;
+  unsigned char *d = dst + (size_t)blockIdx.y * row_stride;
+  size_t const n16 = bytes / 16, step = (size_t)gridDim.x * blockDim.x;
+  typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+  const u32x4 *s4 = reinterpret_cast<const u32x4 *>(s);
+  u32x4 *d4 = reinterpret_cast<u32x4 *>(d);
+  size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  for (; k + 3 * step < n16; k += 4 * step) {
+    u32x4 const a = __builtin_nontemporal_load(s4 + k), b = __builtin_nontemporal_load(s4 + k + step),
+                c = __builtin_nontemporal_load(s4 + k + 2 * step), e = __builtin_nontemporal_load(s4 + k + 3 * step);
+    d4[k] = a, d4[k + step] = b, d4[k + 2 * step] = c, d4[k + 3 * step] = e;
+  }
+  for (; k < n16; k += step) d4[k] = __builtin_nontemporal_load(s4 + k);
+  for (size_t t = n16 * 16 + (size_t)blockIdx.x * blockDim.x + threadIdx.x; t < bytes; t += step) d[t] = s[t];
+}
+int launch_host_pull(hipStream_t st, const void *src_host_mapped, void *dst, size_t row_stride_bytes, size_t bytes, int nrows) {
+  if (bytes == 0 || nrows <= 0) return 0;
+  int gx = (int)((bytes / 16 + 4 * 256 - 1) / (4 * 256));
+  gx = gx < 1 ? 1 : gx > 32 ? 32 : gx;
+  hipLaunchKernelGGL(kh_host_pull, dim3(gx, nrows), dim3(256), 0, st, static_cast<const unsigned char *>(src_host_mapped),
+                     static_cast<unsigned char *>(dst), row_stride_bytes, bytes);
+  return KH_HIP(hipGetLastError()) ? 0 : -1;
+}
+
 // ================================================================ notch: filter.c:719-727
 // One-pole notch at the mixer frequency: spin down, subtract and track the DC term, spin back up.  The recurrence runs
 // through every sample (dcstate and the fp64 phasor), in the reference's order of operations and precisions: one lane.

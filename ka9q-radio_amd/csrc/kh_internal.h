@@ -212,7 +212,8 @@ int launch_demod(hipStream_t st, float2 *baseband, size_t bb_stride, int olen, i
                  const DemodDesc *desc, DemodState *state, float *audio, int16_t *pcm, size_t pcm_stride,
                  int pcm_big_endian, void *status /*kh_status[nchan][max_blocks]*/, int status_stride,
                  const int *fm_list, int n_fm, const int *lin_list, int n_lin, const int *am_list, int n_am,
-                 const FmScratch &fm, const N0FinalArgs *n0final = nullptr);
+                 const FmScratch &fm, const N0FinalArgs *n0final = nullptr, int n_lin_nopll = 0);
+// (lin_list: the channels without PLL first; n_lin_nopll of them)
 // n0final (may be null): kh_n0_final's work rides in the FM finish launch; only valid if fm_finish_wave_usable() and n_fm > 0
 int fm_finish_wave_usable(int olen, int nblocks);
 
@@ -236,6 +237,7 @@ int launch_decimate(hipStream_t st, float *rails, size_t rail_stride, int nrails
                     int stage_threshold, void *hb15_states, float *hb3_states);
 // copy count elements of elem_bytes from src to dst for each of n rows (overlap-save history carry, filter.c:230)
 int launch_carry(hipStream_t st, const void *src, void *dst, size_t row_stride_bytes, size_t bytes, int nrows);
+int launch_host_pull(hipStream_t st, const void *src_host_mapped, void *dst, size_t row_stride_bytes, size_t bytes, int nrows);
 
 // ---------------------------------------------------------------- packet.c (kh_packet_kernels.hip, kh_packet.cpp)
 struct AfskState { // the locals of decode_task (packet.c:410-435) and sp->rtp_state_out, one per session

@@ -25,7 +25,7 @@ EXPORTS = [
     "set_filter", "noise_gain", "hb15_block", "hb3_block", "kh_decimate_rails",
     "kh_bank_create", "kh_bank_destroy", "kh_bank_set_channel", "kh_bank_set_lo", "kh_bank_set_second_lo", "kh_bank_set_doppler", "kh_bank_write_input",
     "kh_bank_write_zeros", "kh_bank_set_gain", "kh_bank_raw_device_ptr", "kh_bank_commit_input",
-    "kh_bank_stream_open", "kh_bank_stream_slot", "kh_bank_stream_submit", "kh_bank_stream_close", "kh_bank_read_pcm_all",
+    "kh_bank_debug_pending", "kh_bank_stream_open", "kh_bank_stream_slot", "kh_bank_stream_submit", "kh_bank_stream_close", "kh_bank_read_pcm_all",
     "kh_bank_execute", "kh_bank_sync", "kh_bank_read_baseband", "kh_bank_read_pcm", "kh_bank_read_audio",
     "kh_bank_read_status", "kh_bank_read_input_status", "kh_bank_read_spectrum", "kh_bank_read_response",
     "kh_bank_pcm_device_ptr", "kh_bank_keep_audio", "kh_bank_keep_baseband", "kh_bank_use_graph", "kh_bank_stream", "kh_bank_profile", "kh_bank_stage_times",
@@ -161,6 +161,7 @@ def lib():
     L.kh_bank_commit_input.argtypes = [C.c_void_p, C.c_uint, C.c_size_t]
     L.kh_bank_execute.argtypes = [C.c_void_p, C.c_uint]
     L.kh_bank_sync.argtypes = [C.c_void_p]
+    L.kh_bank_debug_pending.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t]
     L.kh_bank_stream_open.argtypes = [C.c_void_p, C.c_uint]
     L.kh_bank_stream_slot.restype = C.c_void_p
     L.kh_bank_stream_slot.argtypes = [C.c_void_p, C.c_uint, C.POINTER(C.c_size_t)]
@@ -388,6 +389,11 @@ class Bank:
             out = np.empty((self.C, nw), np.int16)
         _check(self.lib.kh_bank_read_pcm_all(self.h, out.ctypes.data, nw), "kh_bank_read_pcm_all")
         return out
+
+    def debug_pending(self):
+        buf = C.create_string_buffer(512)
+        self.lib.kh_bank_debug_pending(self.h, buf, 512)
+        return buf.value.decode()
 
     def stream_open(self, depth):
         _check(self.lib.kh_bank_stream_open(self.h, depth), "kh_bank_stream_open")

@@ -1,5 +1,5 @@
 """Streaming ingest (kh_bank_stream_*): wire-format samples written into the library's pinned host ring and moved to the
-device by hipMemcpyAsync on a copy stream (the north_star's host side; replaces proc_samples' per-packet loop,
+device on a copy stream by the transfer kernel, or by the copy engines (the north_star's host side; replaces proc_samples' per-packet loop,
 radio.c:132-191).  Same kernels, same samples as kh_bank_write_input + kh_bank_execute, so every result must be
 bit-identical -- whatever the ring depth, with several submits in flight and with launches of different lengths."""
 import numpy as np
@@ -10,8 +10,15 @@ import synth
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("payload_name,depth", [("KH_PT_IQ16LE", 2), ("KH_PT_IQ16LE", 4), ("KH_PT_CF32", 3)])
-def test_stream_matches_write_input(hip, payload_name, depth):
+@pytest.mark.parametrize("payload_name,depth,env", [
+    ("KH_PT_IQ16LE", 2, {}), ("KH_PT_IQ16LE", 4, {}), ("KH_PT_CF32", 3, {}),
+    ("KH_PT_IQ16LE", 3, {"KA9Q_HIP_STREAM_SDMA": "0"}),      # kh_host_pull instead of hipMemcpyAsync
+    ("KH_PT_CF32", 2, {"KA9Q_HIP_STREAM_HOSTWAIT": "1"}),    # the host, not the front stream, waits for the transfer
+    ("KH_PT_IQ16LE", 2, {"KA9Q_HIP_PIPELINE": "0"}),         # one compute stream
+])
+def test_stream_matches_write_input(hip, monkeypatch, payload_name, depth, env):
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
     fs, L, M, D, C, T = 8_000_000, 131072, 131073, 256, 6, 3
     N = L + M - 1
     payload = getattr(hip, payload_name)

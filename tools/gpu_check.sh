@@ -14,11 +14,11 @@ for l in open(sys.argv[1]):
         d=json.loads(l); print(sys.argv[1].split('/')[-1], "ms/step", d["ms_per_step"], "MS/s", d["value"], {k:round(v["ms"]*1e3,1) for k,v in d["stages"].items()}, d["roofline"]["kernel"], d["roofline"]["frac"])
 PY
 }
-timeout -k 10 200 python bench.py --no-cpu > gpurun_out/bench_$tag.log 2>&1 || { tail -5 gpurun_out/bench_$tag.log; exit 1; }
+timeout -k 10 200 python bench.py --no-cpu --no-extra > gpurun_out/bench_$tag.log 2>&1 || { tail -5 gpurun_out/bench_$tag.log; exit 1; }
 summ gpurun_out/bench_$tag.log
 i=0
 for e in "$@"; do
   i=$((i+1))
-  env $e timeout -k 10 200 python bench.py --no-cpu > gpurun_out/bench_${tag}_$i.log 2>&1 || { tail -5 gpurun_out/bench_${tag}_$i.log; exit 1; }
+  env $e timeout -k 10 200 python bench.py --no-cpu --no-extra > gpurun_out/bench_${tag}_$i.log 2>&1 || { tail -5 gpurun_out/bench_${tag}_$i.log; exit 1; }
   echo "$e"; summ gpurun_out/bench_${tag}_$i.log
 done

@@ -6,7 +6,7 @@ R=$GRAFT_REPO_ROOT
 out=$R/gpurun_out/$tag
 mkdir -p $out
 cd /tmp && export TMPDIR=/tmp
-timeout -s KILL 120 rocprofv3 --pmc $ctrs --output-format csv -d $out -o pmc -- python3 $R/bench.py --no-cpu --steps 5 --warmup 2 "$@" > $out/pmc.log 2>&1
+timeout -s KILL 120 rocprofv3 --pmc $ctrs --output-format csv -d $out -o pmc -- python3 $R/bench.py --no-cpu --no-extra --steps 5 --warmup 2 "$@" > $out/pmc.log 2>&1
 f=$(find $out -name '*counter_collection.csv' | head -1)
 python3 - "$f" <<'PY'
 import csv,sys,collections

@@ -6,7 +6,7 @@ out=gpurun_out/$tag
 mkdir -p $out
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
-timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/$out/kt -o kt -- python3 $R/bench.py --no-cpu "$@" > $R/$out/kt.log 2>&1
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/$out/kt -o kt -- python3 $R/bench.py --no-cpu --no-extra "$@" > $R/$out/kt.log 2>&1
 f=$(find $R/$out/kt -name '*kernel_stats.csv' | head -1)
 python3 - "$f" <<'PY'
 import csv,sys
