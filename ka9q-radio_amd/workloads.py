@@ -74,13 +74,31 @@ def config2_plan(n_channels=64):
     return raster_fm_plan(CONFIG2, range(-(n_channels // 2), n_channels - n_channels // 2))
 
 
-def config3_plan(n_channels=1024):
-    """C3: k mod 4 = 0, 1 -> NBFM; 2 -> envelope AM; 3 -> USB; k = -n/2 .. n/2-1"""
+def mixed_plan(shape, n_channels):
+    """C3's rule on any shape: k mod 4 = 0, 1 -> NBFM; 2 -> envelope AM; 3 -> USB; k = -n/2 .. n/2-1"""
     plan = []
     for j, k in enumerate(range(-(n_channels // 2), n_channels - n_channels // 2)):
         m = k % 4
-        plan.append(fm_channel(CONFIG3, k, j) if m in (0, 1) else am_channel(CONFIG3, k, j) if m == 2 else usb_channel(CONFIG3, k, j))
+        plan.append(fm_channel(shape, k, j) if m in (0, 1) else am_channel(shape, k, j) if m == 2 else usb_channel(shape, k, j))
     return plan
+
+
+def config3_plan(n_channels=1024):
+    return mixed_plan(CONFIG3, n_channels)
+
+
+def plan_signal(plan, shape, n0, nsamples, sigma=0.01):
+    """the wideband input a plan describes: noise + one FM / AM / two-tone USB signal per channel at its bin centre"""
+    x = synth.noise(nsamples, sigma).astype(np.complex128)
+    for ch in plan:
+        fc = ch["rotate"] * shape.fs / shape.N
+        if ch["kind"] == "fm":
+            x += synth.fm_carrier(n0, nsamples, shape.fs, fc, ch["amp"], ch["tone"], ch["deviation"], phase0=0.1 * ch["k"])
+        elif ch["kind"] == "am":
+            x += synth.am_carrier(n0, nsamples, shape.fs, fc, ch["amp"], ch["tone"], ch["depth"], phase0=0.3)
+        elif ch["kind"] == "usb":
+            x += synth.usb_two_tone(n0, nsamples, shape.fs, fc, ch["amp"])
+    return x.astype(np.complex64)
 
 
 def config4_plan(n_channels=4096):
