@@ -1378,6 +1378,176 @@ __global__ void kh_hb3_state(const float *__restrict__ in, size_t rail_stride, i
   states[r * state_stride + state_index] = in[(size_t)r * rail_stride + 2 * cnt - 1];
 }
 
+// ---- the whole cascade in one launch (hackrf.c:495-509: log2(D) half-band stages per rail, in place) ----
+// A workgroup owns DEC tile: TO final outputs of one rail.  It loads the raw samples they depend on into LDS (TO << ld
+// of them plus the 13 (2^ld - 1) the 15-tap stages reach back), runs every stage from LDS to LDS with the formulas of
+// kh_hb15 / kh_hb3 above (same expressions, so the same floats), and stores TO floats.  Samples before the start of the
+// call come from each stage's carried state exactly where the staged kernels take them (hb15_hist).  The workgroup of
+// the last tile leaves every stage's new state (decimate.c:145-147, :162) in a second state buffer: the first tiles may
+// still be reading the old one.
+// algorithmic bytes per rail and call: 4 (chunk << ld) read + 4 chunk written; the halo re-reads hit L2.
+constexpr int DEC_LDS_FLOATS = 15872; // 62 KB: raw tile + halo (A), and the first stage's output (B)
+
+__device__ __forceinline__ float dec_hist(const Hb15Dev *s15, const float *s3, int slot, bool is15, int idx) {
+  if (idx < -14) return 0.f; // never read: the lowest tap of an output k >= 0 is x[-13]
+  if (is15) return hb15_hist(s15[slot], idx);
+  return idx == -1 ? s3[slot] : 0.f;
+}
+
+// one stage, LDS to LDS: dst[k - dlo] for k in [dlo, dhi] from src[idx - slo].  EDGE: the tile reaches back before the
+// start of the call (only the first tile of a rail does), so taps and outputs at negative indices come from the states.
+template <bool EDGE>
+__device__ __forceinline__ void dec_stage(const float *src, float *dst, int slo, int dlo, int dhi, bool is15, int slot, bool n15,
+                                          const Hb15Dev *__restrict__ s15_in, const float *__restrict__ s3_in) {
+  int const tid = threadIdx.x;
+  auto X = [&](int idx) -> float {
+    if (EDGE && idx < 0) return dec_hist(s15_in, s3_in, slot, is15, idx);
+    return src[idx - slo];
+  };
+  if (is15) {
+    float const c0 = s15_in[slot].coeffs[0], c1 = s15_in[slot].coeffs[1], c2 = s15_in[slot].coeffs[2], c3 = s15_in[slot].coeffs[3];
+    for (int t = tid; t <= dhi - dlo; t += 256) {
+      int const k = dlo + t;
+      float result;
+      if (!EDGE || k >= 0) {
+        result = X(2 * k - 6);
+        result += (X(2 * k + 1) + X(2 * k - 13)) * c0;
+        result += (X(2 * k - 1) + X(2 * k - 11)) * c1;
+        result += (X(2 * k - 3) + X(2 * k - 9)) * c2;
+        result += (X(2 * k - 5) + X(2 * k - 7)) * c3;
+      } else {
+        result = dec_hist(s15_in, s3_in, slot - 1, n15, k); // what the next stage's state holds for this sample
+      }
+      dst[t] = result;
+    }
+  } else {
+    for (int t = tid; t <= dhi - dlo; t += 256) {
+      int const k = dlo + t;
+      dst[t] = (!EDGE || k >= 0) ? 2 * X(2 * k) + X(2 * k + 1) + X(2 * k - 1) : dec_hist(s15_in, s3_in, slot - 1, n15, k);
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void kh_decimate_fused(const float *__restrict__ in, size_t in_stride, float *__restrict__ out,
+                                                         size_t out_stride, int chunk, int ld, int thr, int TO, int a_cap,
+                                                         const Hb15Dev *__restrict__ s15_in, Hb15Dev *__restrict__ s15_out,
+                                                         const float *__restrict__ s3_in, float *__restrict__ s3_out) {
+  extern __shared__ float dec_lds[];
+  float *const A = dec_lds, *const B = dec_lds + a_cap;
+  int const r = blockIdx.y, tid = threadIdx.x;
+  int const k0 = blockIdx.x * TO, k1 = min(chunk, k0 + TO) - 1;
+  bool const last = blockIdx.x == gridDim.x - 1;
+  // [lo, hi] of stage j's output (j = ld: the raw samples), in that stream's own index space
+  auto range = [&](int j, int &lo, int &hi) {
+    lo = k0, hi = k1;
+    for (int q = 0; q < j; q++) {
+      lo = 2 * lo - (q < thr ? 13 : 1);
+      hi = 2 * hi + 1;
+    }
+  };
+  int slo, shi;
+  range(ld, slo, shi);
+  bool const edge = slo < 0; // then some stage reads before the call's first sample; otherwise none does
+  slo = max(slo, -14);
+  {
+    const float *x = in + (size_t)r * in_stride;
+    int const slot = r * ld + (ld - 1);
+    bool const is15 = (ld - 1) < thr;
+    for (int t = tid; t <= shi - slo; t += 256) {
+      int const idx = slo + t;
+      A[t] = idx >= 0 ? x[idx] : dec_hist(s15_in, s3_in, slot, is15, idx);
+    }
+  }
+  __syncthreads();
+  float *src = A, *dst = B;
+  for (int j = ld - 1; j >= 0; j--) {
+    int const slot = r * ld + j;
+    bool const is15 = j < thr;
+    if (last && tid == 0) { // the carried state of stage j after cnt outputs, from the stage's input stream
+      int const cnt = chunk << j;
+      auto X = [&](int idx) -> float { return idx >= 0 ? src[idx - slo] : dec_hist(s15_in, s3_in, slot, is15, idx); };
+      Hb15Dev n = s15_in[slot];
+      float n3 = s3_in[slot];
+      if (is15) {
+        n.even_samples[0] = X(2 * (cnt - 1));
+        n.even_samples[1] = X(2 * (cnt - 1));
+        n.even_samples[2] = X(2 * (cnt - 2));
+        n.even_samples[3] = X(2 * (cnt - 3));
+        n.odd_samples[0] = X(2 * (cnt - 1) + 1);
+        n.odd_samples[1] = X(2 * (cnt - 1) + 1);
+        n.odd_samples[2] = X(2 * (cnt - 2) + 1);
+        n.odd_samples[3] = X(2 * (cnt - 3) + 1);
+        n.old_odd_samples[3] = X(2 * (cnt - 4) + 1);
+        n.old_odd_samples[2] = X(2 * (cnt - 5) + 1);
+        n.old_odd_samples[1] = X(2 * (cnt - 6) + 1);
+        n.old_odd_samples[0] = X(2 * (cnt - 7) + 1);
+      } else {
+        n3 = X(2 * cnt - 1);
+      }
+      s15_out[slot] = n;
+      s3_out[slot] = n3;
+    }
+    int dlo, dhi;
+    range(j, dlo, dhi);
+    dlo = max(dlo, -14);
+    bool const n15 = (j - 1) < thr; // the type of the stage that consumes this one's output (j >= 1)
+    if (edge)
+      dec_stage<true>(src, dst, slo, dlo, dhi, is15, slot, n15, s15_in, s3_in);
+    else
+      dec_stage<false>(src, dst, slo, dlo, dhi, is15, slot, n15, s15_in, s3_in);
+    __syncthreads();
+    float *const tmp = src;
+    src = dst;
+    dst = tmp;
+    slo = dlo, shi = dhi;
+  }
+  for (int t = tid; t <= k1 - k0; t += 256) out[(size_t)r * out_stride + k0 + t] = src[t];
+}
+
+// The tile: TO final outputs from raw = TO << ld samples plus the halo.  The largest raw tile that fits the LDS budget
+// wastes the fewest re-reads, a smaller one gives short calls enough workgroups to fill the chip and more workgroups per
+// CU; raw tiles of 1024-2048 measured best for long rails (1.3-1.4 TB/s of algorithmic bytes against 0.74 at 4096-8192) (tools/decimate_bench.py).  Returns 0 when the cascade is too deep.
+static int decimate_tile(int ld, int thr, int nrails, int chunk, int *a_cap, int *b_cap) {
+  long halo = 0;
+  for (int q = 0; q < ld; q++) halo = 2 * halo + (q < thr ? 13 : 1);
+  static int const pref = getenv("KA9Q_HIP_DECIMATE_TILE") ? atoi(getenv("KA9Q_HIP_DECIMATE_TILE")) : 2048;
+  int best = 0;
+  for (int raw = 8192; raw >= (1 << ld) && raw >= 256; raw >>= 1) {
+    long const a = raw + halo + 16, b = raw / 2 + halo / 2 + 16;
+    if (a + b > DEC_LDS_FLOATS) continue;
+    if (best == 0) best = raw; // the largest that fits
+    // go smaller while the launch would leave CUs idle (fewer than two workgroups each) or down to the preferred size
+    long const wgs = (long)nrails * (((long)chunk << ld) + raw - 1) / raw;
+    if (raw > pref || wgs < 512) best = raw;
+    else break;
+  }
+  if (best == 0) return 0;
+  *a_cap = (int)(best + halo + 16);
+  *b_cap = (int)(best / 2 + halo / 2 + 16);
+  return best >> ld;
+}
+bool decimate_can_fuse(int log_decimate, int stage_threshold) {
+  int a, b;
+  return log_decimate >= 1 && log_decimate <= 12 && decimate_tile(log_decimate, stage_threshold, 1, 1 << 20, &a, &b) >= 1;
+}
+// in: nrails rails of chunk << ld floats (device); out: nrails rails of chunk floats (device, not overlapping `in`);
+// states_*: nrails*ld entries each, in != out
+int launch_decimate_fused(hipStream_t st, const float *in, size_t in_stride, float *out, size_t out_stride, int nrails, int chunk,
+                          int log_decimate, int stage_threshold, const void *hb15_in, void *hb15_out, const float *hb3_in,
+                          float *hb3_out) {
+  if (nrails <= 0 || chunk <= 0 || log_decimate <= 0) return 0;
+  int a_cap = 0, b_cap = 0;
+  int const TO = decimate_tile(log_decimate, stage_threshold, nrails, chunk, &a_cap, &b_cap);
+  if (TO < 1) {
+    set_error("launch_decimate_fused: 2^%d:1 does not fit one launch", log_decimate);
+    return -1;
+  }
+  hipLaunchKernelGGL(kh_decimate_fused, dim3((chunk + TO - 1) / TO, nrails), dim3(256), (a_cap + b_cap) * sizeof(float), st, in,
+                     in_stride, out, out_stride, chunk, log_decimate, stage_threshold, TO, a_cap,
+                     static_cast<const Hb15Dev *>(hb15_in), static_cast<Hb15Dev *>(hb15_out), hb3_in, hb3_out);
+  return KH_HIP(hipGetLastError()) ? 0 : -1;
+}
+
 // rails: two device buffers of nrails*rail_stride floats are needed (ping-pong); `rails` holds the input in its
 // first half [0, nrails*rail_stride) and scratch in the second.  The result ends in the first half.
 int launch_decimate(hipStream_t st, float *rails, size_t rail_stride, int nrails, int chunk, int log_decimate,

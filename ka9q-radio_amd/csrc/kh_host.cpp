@@ -671,36 +671,92 @@ kh_cf32 notch(struct notchfilter *nf, kh_cf32 s) {
 }
 
 // ------------------------------------------------------------------ decimate.h
-// buf/outbuf/state pointers may be host or device memory (hipMemcpyDefault resolves the direction)
+// buf/outbuf/state pointers may be host or device memory.  The device-side working memory is kept between calls and
+// only grows (hackrf.c calls this once per USB transfer: no allocation on that path after the first transfer); calls
+// are serialised on it.
+struct DecScratch {
+  float *in = nullptr, *out = nullptr; // rails x len staged input (host callers, deep cascades), rails x chunk output
+  size_t in_cap = 0, out_cap = 0;      // floats
+  char *s15[2] = {nullptr, nullptr};   // hb15 states before / after the call
+  float *s3[2] = {nullptr, nullptr};
+  int nstate_cap = 0;
+};
+static DecScratch g_dec;
+static std::mutex g_dec_mutex;
+
+static bool dec_reserve(float **p, size_t *cap, size_t need) {
+  if (need <= *cap) return true;
+  if (*p) (void)hipFree(*p);
+  *p = nullptr, *cap = 0;
+  if (!KH_HIP(hipMalloc((void **)p, need * sizeof(float)))) return false;
+  *cap = need;
+  return true;
+}
+static bool is_device_pointer(const void *p) {
+  hipPointerAttribute_t a;
+  if (hipPointerGetAttributes(&a, p) != hipSuccess) {
+    (void)hipGetLastError(); // plain host memory the runtime has never seen
+    return false;
+  }
+  return a.type == hipMemoryTypeDevice;
+}
+
 static int decimate_host(struct hb15_state *hb15, float *hb3, int log_decimate, int stage_threshold, float *buf,
                          size_t rail_stride, int rails, int chunk, float *outbuf) {
   if (ensure_init()) return -1;
   if (rails <= 0 || chunk <= 0 || log_decimate <= 0) return 0;
+  std::lock_guard<std::mutex> lk(g_dec_mutex);
   hipStream_t st = default_stream();
   size_t const len = (size_t)chunk << log_decimate;
-  float *d = nullptr;
-  char *dstate = nullptr;
-  float *dhb3 = nullptr;
   int const nstate = rails * log_decimate;
-  bool ok = KH_HIP(hipMalloc(&d, 2 * rails * len * sizeof(float)));
-  ok = ok && KH_HIP(hipMalloc(&dstate, nstate * sizeof(struct hb15_state)));
-  ok = ok && KH_HIP(hipMalloc(&dhb3, nstate * sizeof(float)));
-  for (int r = 0; r < rails && ok; r++)
-    ok = KH_HIP(hipMemcpyAsync(d + r * len, buf + r * rail_stride, len * sizeof(float), hipMemcpyDefault, st));
-  if (ok && hb15) ok = KH_HIP(hipMemcpyAsync(dstate, hb15, nstate * sizeof(struct hb15_state), hipMemcpyDefault, st));
-  if (ok && hb3) ok = KH_HIP(hipMemcpyAsync(dhb3, hb3, nstate * sizeof(float), hipMemcpyDefault, st));
-  int rc = ok ? launch_decimate(st, d, len, rails, chunk, log_decimate, stage_threshold, dstate, dhb3) : -1;
+  DecScratch &D = g_dec;
+  if (nstate > D.nstate_cap) {
+    for (int k = 0; k < 2; k++) {
+      if (D.s15[k]) (void)hipFree(D.s15[k]);
+      if (D.s3[k]) (void)hipFree(D.s3[k]);
+      D.s15[k] = nullptr, D.s3[k] = nullptr;
+    }
+    D.nstate_cap = 0;
+    bool ok = true;
+    for (int k = 0; k < 2 && ok; k++)
+      ok = KH_HIP(hipMalloc((void **)&D.s15[k], nstate * sizeof(struct hb15_state))) && KH_HIP(hipMalloc((void **)&D.s3[k], nstate * sizeof(float)));
+    if (!ok) return -1;
+    D.nstate_cap = nstate;
+  }
+  const char *const e = getenv("KA9Q_HIP_DECIMATE_FUSED"); // 0: one launch pair per stage (the round-1 route; tests compare the two)
+  bool const fuse = !(e && atoi(e) == 0) && decimate_can_fuse(log_decimate, stage_threshold);
+  bool const direct = fuse && is_device_pointer(buf); // the fused kernel reads the caller's rails where they lie
+  // staged cascade: input and ping-pong half in one buffer; fused from host memory: the input only
+  if (!direct && !dec_reserve(&D.in, &D.in_cap, (fuse ? 1 : 2) * (size_t)rails * len)) return -1;
+  if (fuse && !dec_reserve(&D.out, &D.out_cap, (size_t)rails * chunk)) return -1;
+  bool ok = true;
+  for (int r = 0; r < rails && ok && !direct; r++)
+    ok = KH_HIP(hipMemcpyAsync(D.in + r * len, buf + r * rail_stride, len * sizeof(float), hipMemcpyDefault, st));
+  // a state the caller does not pass still has to be defined where a stage would read it: zero
+  if (ok) ok = hb15 ? KH_HIP(hipMemcpyAsync(D.s15[0], hb15, nstate * sizeof(struct hb15_state), hipMemcpyDefault, st))
+                    : KH_HIP(hipMemsetAsync(D.s15[0], 0, nstate * sizeof(struct hb15_state), st));
+  if (ok) ok = hb3 ? KH_HIP(hipMemcpyAsync(D.s3[0], hb3, nstate * sizeof(float), hipMemcpyDefault, st))
+                   : KH_HIP(hipMemsetAsync(D.s3[0], 0, nstate * sizeof(float), st));
+  int rc = ok ? 0 : -1;
+  const float *result = nullptr;
+  size_t result_stride = 0;
+  int after = 0; // which state buffer holds the states after the call
+  if (!rc && fuse) {
+    rc = launch_decimate_fused(st, direct ? buf : D.in, direct ? rail_stride : len, D.out, chunk, rails, chunk, log_decimate,
+                               stage_threshold, D.s15[0], D.s15[1], D.s3[0], D.s3[1]);
+    result = D.out, result_stride = chunk, after = 1;
+  } else if (!rc) {
+    rc = launch_decimate(st, D.in, len, rails, chunk, log_decimate, stage_threshold, D.s15[0], D.s3[0]);
+    result = D.in, result_stride = len;
+  }
   for (int r = 0; r < rails && !rc; r++)
-    rc = KH_HIP(hipMemcpyAsync((outbuf ? outbuf : buf) + r * rail_stride, d + r * len, chunk * sizeof(float),
+    rc = KH_HIP(hipMemcpyAsync((outbuf ? outbuf : buf) + r * rail_stride, result + r * result_stride, chunk * sizeof(float),
                                hipMemcpyDefault, st))
              ? 0
              : -1;
-  if (!rc && hb15) rc = KH_HIP(hipMemcpyAsync(hb15, dstate, nstate * sizeof(struct hb15_state), hipMemcpyDefault, st)) ? 0 : -1;
-  if (!rc && hb3) rc = KH_HIP(hipMemcpyAsync(hb3, dhb3, nstate * sizeof(float), hipMemcpyDefault, st)) ? 0 : -1;
+  if (!rc && hb15) rc = KH_HIP(hipMemcpyAsync(hb15, D.s15[after], nstate * sizeof(struct hb15_state), hipMemcpyDefault, st)) ? 0 : -1;
+  if (!rc && hb3) rc = KH_HIP(hipMemcpyAsync(hb3, D.s3[after], nstate * sizeof(float), hipMemcpyDefault, st)) ? 0 : -1;
   if (!rc) rc = KH_HIP(hipStreamSynchronize(st)) ? 0 : -1;
-  if (d) hipFree(d);
-  if (dstate) hipFree(dstate);
-  if (dhb3) hipFree(dhb3);
   return rc;
 }
 int kh_decimate_rails(struct hb15_state *hb15, float *hb3, int log_decimate, int stage_threshold, float *buf,

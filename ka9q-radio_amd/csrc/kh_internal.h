@@ -235,6 +235,10 @@ int launch_notch(hipStream_t st, NotchState *state, float2 *buf, int n);
 // decimate.c
 int launch_decimate(hipStream_t st, float *rails, size_t rail_stride, int nrails, int chunk, int log_decimate,
                     int stage_threshold, void *hb15_states, float *hb3_states);
+bool decimate_can_fuse(int log_decimate, int stage_threshold);
+int launch_decimate_fused(hipStream_t st, const float *in, size_t in_stride, float *out, size_t out_stride, int nrails, int chunk,
+                          int log_decimate, int stage_threshold, const void *hb15_in, void *hb15_out, const float *hb3_in,
+                          float *hb3_out);
 // copy count elements of elem_bytes from src to dst for each of n rows (overlap-save history carry, filter.c:230)
 int launch_carry(hipStream_t st, const void *src, void *dst, size_t row_stride_bytes, size_t bytes, int nrows);
 int launch_host_pull(hipStream_t st, const void *src_host_mapped, void *dst, size_t row_stride_bytes, size_t bytes, int nrows);

@@ -215,7 +215,8 @@ def test_hb15_and_hb3_block(hip):
     assert np.abs(a[:1024] - b[:1024]).max() <= 2e-6
 
 
-@pytest.mark.parametrize("logd,thresh,chunk", [(6, 8, 480), (3, 8, 1000), (10, 8, 60), (1, 8, 4096)])
+@pytest.mark.parametrize("logd,thresh,chunk", [(6, 8, 480), (3, 8, 1000), (10, 8, 60), (1, 8, 4096), (6, 8, 5000), (6, 3, 517),
+                                               (9, 8, 37), (8, 2, 100), (6, 8, 1), (4, 8, 5), (7, 0, 300)])
 def test_decimation_cascade_rails(hip, logd, thresh, chunk):
     """hackrf.c:495-509: both rails through log2(D) in-place stages, hb3 for stages j >= stage_threshold (D >= 512),
     hb15 below; three consecutive chunks to exercise every stage's state carry.  64:1 at chunk 480 is the
@@ -242,3 +243,31 @@ def test_decimation_cascade_rails(hip, logd, thresh, chunk):
             Lo.orc_decimate_rail(so[r], h3o[r].ctypes.data_as(C.c_void_p), logd, thresh, o.ctypes.data_as(C.c_void_p), chunk)
             scale = np.abs(o[:chunk]).max()
             assert np.abs(g[r, :chunk] - o[:chunk]).max() <= 1e-5 * scale, (r, _rep)
+
+
+@pytest.mark.parametrize("logd,thresh,chunks", [(6, 8, [480, 1, 3, 129, 1000]), (5, 2, [64, 7, 2000]), (9, 8, [16, 17, 5]),
+                                                (2, 8, [3000, 2, 9000])])
+def test_fused_cascade_equals_the_staged_one(hip, monkeypatch, logd, thresh, chunks):
+    """The one-launch cascade (kh_decimate_fused: LDS tiles with halos, state from the last tile) against one launch pair
+    per stage (KA9Q_HIP_DECIMATE_FUSED=0), both with the formulas of decimate.c:124-147,150-163: every output and every
+    carried state bit for bit, over consecutive calls of different lengths (tiles that start in the carried history, a last
+    tile shorter than the history, one-sample calls)."""
+    global hip_Hb15
+    hip_Hb15 = hip.Hb15State
+    rng = np.random.default_rng(100 + logd)
+    Lh = hip.lib()
+    rails = 2
+    sa, sb = _f8_states(rails * logd), _f8_states(rails * logd)
+    ha, hb = np.zeros(rails * logd, np.float32), np.zeros(rails * logd, np.float32)
+    for chunk in chunks:
+        n = chunk << logd
+        x = rng.uniform(-1, 1, (rails, n)).astype(np.float32)
+        a, b = x.copy(), x.copy()
+        monkeypatch.setenv("KA9Q_HIP_DECIMATE_FUSED", "1")
+        assert Lh.kh_decimate_rails(sa, ha.ctypes.data, logd, thresh, a.ctypes.data, n, rails, chunk) == 0, hip.last_error()
+        monkeypatch.setenv("KA9Q_HIP_DECIMATE_FUSED", "0")
+        assert Lh.kh_decimate_rails(sb, hb.ctypes.data, logd, thresh, b.ctypes.data, n, rails, chunk) == 0, hip.last_error()
+        assert np.array_equal(a[:, :chunk], b[:, :chunk]), chunk
+        assert np.array_equal(a[:, chunk:], x[:, chunk:]), chunk  # the fused route leaves the rest of the caller's rails alone
+        assert bytes(sa) == bytes(sb), chunk
+        assert np.array_equal(ha, hb), chunk
