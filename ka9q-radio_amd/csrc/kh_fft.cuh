@@ -122,11 +122,13 @@ __device__ __forceinline__ float2 buf_load2(__amdgpu_buffer_rsrc_t r, int voff, 
   kh_u32x2 const t = __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, 0);
   return make_float2(__uint_as_float(t.x), __uint_as_float(t.y));
 }
+// AUX: the instruction's cache policy bits (gfx942/gfx950: 1 = sc0, 2 = nt, 16 = sc1)
+template <int AUX = 0>
 __device__ __forceinline__ void buf_store2(float2 v, __amdgpu_buffer_rsrc_t r, int voff, int soff) {
   kh_u32x2 t;
   t.x = __float_as_uint(v.x);
   t.y = __float_as_uint(v.y);
-  __builtin_amdgcn_raw_buffer_store_b64(t, r, voff, soff, 0);
+  __builtin_amdgcn_raw_buffer_store_b64(t, r, voff, soff, AUX);
 }
 
 } // namespace kh

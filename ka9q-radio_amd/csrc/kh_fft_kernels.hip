@@ -433,7 +433,12 @@ __global__ __launch_bounds__(NT, 4) void kh_fft_cols(const float2 *__restrict__ 
   }
 }
 
-template <int RA, int RB, int NT, bool DIRECT>
+// SPEC_AUX: cache policy of the spectrum stores.  A launch whose spectrum alone is beyond ~100 MB (N >= 2^19 at the bench
+// shapes) stores it non-temporal (2): the spectrum is read once, much later, by the channel kernels, while the raw ring and
+// the intermediate of the transform are re-read at once and fit the 256 MiB Infinity Cache only if the spectrum does not
+// push them out.  Measured: config 3's share 176 -> 157 us/step, config 4's 164 -> 152; nothing at configs[1], where
+// everything fits (nt on the raw loads, or sc0 / sc1 on these stores, measured worse).
+template <int RA, int RB, int NT, bool DIRECT, int SPEC_AUX>
 __global__ __launch_bounds__(NT, 4) void kh_fft_rows(const float2 *__restrict__ tmp, float2 *__restrict__ spec,
                                                   size_t spec_in_stride, int N1, const float2 *__restrict__ tw,
                                                   N0Fuse n0, int b0, int nblocks) {
@@ -506,7 +511,7 @@ __global__ __launch_bounds__(NT, 4) void kh_fft_rows(const float2 *__restrict__ 
       for (int d = 0; d < RB; d++) {
         int const k2 = c + RA * d;
         float2 const x = z[d];
-        buf_store2(x, rout, (c * N1 + w) * 8, RA * d * N1 * 8); // X[k1 + N1*k2], k1 = tile*W + w
+        buf_store2<SPEC_AUX>(x, rout, (c * N1 + w) * 8, RA * d * N1 * 8); // X[k1 + N1*k2], k1 = tile*W + w
         if (n0.part != nullptr && n0_bin_counts(tile * W + w + N1 * k2, (int)N, n0)) pw += x.x * x.x + x.y * x.y;
       }
     }
@@ -554,7 +559,7 @@ __global__ __launch_bounds__(NT, 4) void kh_fft_rows(const float2 *__restrict__ 
     }
   }
 #pragma unroll
-  for (int d = 0; d < RB; d++) buf_store2(z[d], rout, (c * N1 + w) * 8, RA * d * N1 * 8); // X[k1 + N1*k2], k2 = c + RA*d
+  for (int d = 0; d < RB; d++) buf_store2<SPEC_AUX>(z[d], rout, (c * N1 + w) * 8, RA * d * N1 * 8); // X[k1 + N1*k2], k2 = c + RA*d
   __syncthreads(); // (red is read again below)
   // The block's other tiles: dispatched next to this one, so their sums arrive within microseconds.  The wait is
   // bounded all the same (a workgroup that is not resident cannot be waited for): when it runs out the block's flag
@@ -631,12 +636,18 @@ static int launch_rows(hipStream_t st, const float2 *tmp, float2 *spec, size_t s
                        int ninputs, N0Fuse n0, int b0, int gblocks) {
   const float2 *tw = twiddle_table(RA * RB);
   if (!tw) return -1;
-  if (n0.direct)
-    hipLaunchKernelGGL((kh_fft_rows<RA, RB, NT, true>), dim3(N1 / TILE_W, gblocks, ninputs), dim3(NT), 0, st, tmp, spec,
-                       spec_in_stride, N1, tw, n0, b0, nblocks);
+  static int const nt_env = getenv("KA9Q_HIP_SPEC_NT") ? atoi(getenv("KA9Q_HIP_SPEC_NT")) : -1; // -1: by size
+  size_t const spec_bytes = (size_t)RA * RB * N1 * 8 * (size_t)nblocks * ninputs;            // of the whole call
+  bool const nt = nt_env < 0 ? spec_bytes >= ((size_t)100 << 20) : nt_env != 0;
+  dim3 const grid(N1 / TILE_W, gblocks, ninputs);
+  if (n0.direct && nt)
+    hipLaunchKernelGGL((kh_fft_rows<RA, RB, NT, true, 2>), grid, dim3(NT), 0, st, tmp, spec, spec_in_stride, N1, tw, n0, b0, nblocks);
+  else if (n0.direct)
+    hipLaunchKernelGGL((kh_fft_rows<RA, RB, NT, true, 0>), grid, dim3(NT), 0, st, tmp, spec, spec_in_stride, N1, tw, n0, b0, nblocks);
+  else if (nt)
+    hipLaunchKernelGGL((kh_fft_rows<RA, RB, NT, false, 2>), grid, dim3(NT), 0, st, tmp, spec, spec_in_stride, N1, tw, n0, b0, nblocks);
   else
-    hipLaunchKernelGGL((kh_fft_rows<RA, RB, NT, false>), dim3(N1 / TILE_W, gblocks, ninputs), dim3(NT), 0, st, tmp, spec,
-                       spec_in_stride, N1, tw, n0, b0, nblocks);
+    hipLaunchKernelGGL((kh_fft_rows<RA, RB, NT, false, 0>), grid, dim3(NT), 0, st, tmp, spec, spec_in_stride, N1, tw, n0, b0, nblocks);
   return KH_HIP(hipGetLastError()) ? 0 : -1;
 }
 
@@ -660,10 +671,10 @@ int fused_ingest_tiles(int N) { // IF power partial sums the fused column pass l
   return (N / four_step_n1(N)) / TILE_W; // one per column tile
 }
 
-// blocks per (column pass, row pass) pair of a four-step transform: KA9Q_HIP_FFT_GROUP_MB (default 64) MiB of scratch
+// blocks per (column pass, row pass) pair of a four-step transform: KA9Q_HIP_FFT_GROUP_MB (default 128) MiB of scratch
 // per group, but never fewer blocks than fill the chip once (1024 workgroups of 256 threads, 512 of 512)
 int fft_group_blocks(int N, int nblocks, int ninputs) {
-  static int const mb = getenv("KA9Q_HIP_FFT_GROUP_MB") ? atoi(getenv("KA9Q_HIP_FFT_GROUP_MB")) : 64;
+  static int const mb = getenv("KA9Q_HIP_FFT_GROUP_MB") ? atoi(getenv("KA9Q_HIP_FFT_GROUP_MB")) : 128;
   if (mb <= 0) return nblocks;
   size_t const per_block = (size_t)N * 8 * (size_t)ninputs;
   int g = (int)(((size_t)mb << 20) / per_block);
