@@ -960,20 +960,22 @@ __global__ __launch_bounds__(64) void kh_demod_linear(float2 *__restrict__ baseb
   states[ch] = s;
 }
 
-// ================================================================ linear without PLL: one wavefront per channel
+// ================================================================ linear without PLL: one workgroup per channel
 // linear.c:114-148 when opt.pll is off (SSB, IQ, ISB, envelope AM: every modes.txt entry except CAM / DSB-with-PLL).
-// Only the AGC (linear.c:127-136) chains from sample to sample, and it chains through three numbers: the sample's
-// amplitude, the gain and the hang counter.  So a block is three steps, all in registers (lane l holds samples
-// l, l + 64, ... of the block: K = ceil(olen / 64) of them):
-//   1  all lanes: post-detection shift (radio.c:355-361; the oscillator in closed form from the phase the state holds),
-//      |s|^2, amplitude, and headroom / amplitude (the gain an attack would set);
-//   2  the AGC state machine over the block's amplitudes, sample by sample, in the reference's order and precision:
-//      sample n's two numbers come out of lane n % 64 by v_readlane (a constant lane: the loop is unrolled), every lane
-//      runs the same few instructions on them, and a select leaves the sample's gain in the lane that owns it;
-//   3  all lanes: envelope / mono / stereo output x gain, scaleclip, coalesced stores, level sums.
-// The serial part is ~10 instructions per sample with no memory access, instead of the ~300 of kh_demod_linear's
-// per-sample loop.  algorithmic bytes per (channel, block): 8 olen read + (2 or 4) olen PCM (+ 8 olen baseband
-// rewritten for stereo, linear.c:145).
+// Only the AGC (linear.c:127-136) chains from sample to sample, through three numbers: the sample's amplitude, the gain
+// and the hang counter.  And between two attacks the gain follows a fixed course: constant while the hang counter runs
+// (modes.txt hangs for 1.1 s), then one multiplication by the recovery rate per sample.  So:
+//   phase 1  all LW_WAVES wavefronts, a block each at a time: post-detection shift (radio.c:355-361; the oscillator in
+//            closed form from the phase the state holds), |s|^2, amplitude; the block's largest amplitude and its energy
+//            go to LDS;
+//   phase 2  wavefront 0 walks the blocks in order with the state (gain, hang).  A block that the hang counter outlasts
+//            and whose largest amplitude does not trip the attack test (fl(a * gain) is monotonic in a for gain >= 0, so
+//            then no sample does) leaves the gain alone: note the gain, count the hang down, next block -- a dozen
+//            instructions.  Any other block is worked through on the spot, from attack to attack (agc_row_pass), with the
+//            reference's roundings, and its output written;
+//   phase 3  all wavefronts: the blocks that phase 2 only noted get their output, sample x (one constant) gain.
+// algorithmic bytes per (channel, block): 8 olen read + (2 or 4) olen PCM (+ 8 olen baseband rewritten for stereo,
+// linear.c:145); the second read of phase 3 comes from L2.
 template <int N, typename F>
 __device__ __forceinline__ void static_for(F &&f) { // f(integral_constant<int, 0>) ... f(integral_constant<int, N - 1>)
   if constexpr (N > 0) {
@@ -981,17 +983,24 @@ __device__ __forceinline__ void static_for(F &&f) { // f(integral_constant<int, 
     f(std::integral_constant<int, N - 1>{});
   }
 }
-__device__ __forceinline__ float lane_value(float v, int l) { // v of lane l (a constant), to every lane
-  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l));
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
 }
+constexpr int LW_WAVES = 8;      // wavefronts per channel
+constexpr int LW_MAXB = N0_MAXB; // blocks per launch (LDS notes per block)
 template <int K>
-__global__ __launch_bounds__(64) void kh_demod_linear_w(float2 *__restrict__ baseband, size_t bb_stride, int olen,
-                                                        int nblocks, const DemodDesc *__restrict__ descs,
-                                                        DemodState *__restrict__ states, float *__restrict__ audio,
-                                                        int16_t *__restrict__ pcm, size_t pcm_stride, int big_endian,
-                                                        kh_status *__restrict__ status, int status_stride,
-                                                        const int *__restrict__ list) {
-  int const lane = threadIdx.x;
+__global__ __launch_bounds__(64 * LW_WAVES) void kh_demod_linear_w(float2 *__restrict__ baseband, size_t bb_stride, int olen,
+                                                                   int nblocks, const DemodDesc *__restrict__ descs,
+                                                                   DemodState *__restrict__ states, float *__restrict__ audio,
+                                                                   int16_t *__restrict__ pcm, size_t pcm_stride, int big_endian,
+                                                                   kh_status *__restrict__ status, int status_stride,
+                                                                   const int *__restrict__ list) {
+  __shared__ float sh_max[LW_MAXB], sh_energy[LW_MAXB], sh_gain[LW_MAXB];
+  __shared__ unsigned char sh_done[LW_MAXB]; // 1: phase 2 has written the block itself
+  __shared__ float gtab[66];                                              // recovery products of one row (wavefront 0)
+  int const lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   int const ch = list[blockIdx.x];
   DemodDesc const d = descs[ch];
   DemodState s = states[ch];
@@ -1001,15 +1010,13 @@ __global__ __launch_bounds__(64) void kh_demod_linear_w(float2 *__restrict__ bas
   // the shift oscillator (osc.c:22-50): phasor = cis(2 pi (phase0 + f m)) at sample m of the launch
   bool const shift_active = !(d.shift_freq == 0.0 && s.shift_re == 1.0 && s.shift_im == 0.0);
   double const phase0 = shift_active ? atan2(s.shift_im, s.shift_re) * (0.5 / M_PI) : 0.0;
-  float gain = s.agc_gain;
-  int hang = s.hangcount;
   int const H = (int)d.hangtime;
-  for (int b = 0; b < nblocks; b++) {
-    float2 *yb = y + (size_t)b * olen;
-    // ---- step 1
-    float2 sm[K];
-    float amp[K], gatt[K], gn[K];
-    float energy = 0.f;
+  float const rate = d.recovery_rate, headroom = d.headroom;
+
+  // sample n = lane + 64 j of block b after the shift
+  auto load_block = [&](int b, float2 (&sm)[K], float (&amp)[K], float &energy) {
+    float2 const *yb = y + (size_t)b * olen;
+    energy = 0.f;
 #pragma unroll
     for (int j = 0; j < K; j++) {
       int const n = lane + 64 * j;
@@ -1025,48 +1032,11 @@ __global__ __launch_bounds__(64) void kh_demod_linear_w(float2 *__restrict__ bas
       float const norm = v.x * v.x + v.y * v.y;
       if (n < olen) energy += norm;
       amp[j] = sqrtf(norm);
-      gatt[j] = d.headroom / amp[j];
-      gn[j] = gain;
     }
-    // ---- step 2: linear.c:127-136
-    if (d.agc) {
-      auto agc_step = [&](float &gn_j, float amp_j, float gatt_j, auto lc) {
-        constexpr int l = decltype(lc)::value;
-        float const a = lane_value(amp_j, l), g = lane_value(gatt_j, l);
-        // Every lane computes the same numbers, but the compiler must not know: with provably uniform values it turns
-        // the state machine into scalar compares and a branch per sample, and every hop between the vector and the
-        // scalar side waits out a pipeline (measured: 115 cycles per sample).  As plain per-lane arithmetic it is five
-        // dependent vector instructions.
-        asm volatile("" : "+v"(gain), "+v"(hang));
-        float const t = isnan(gain) ? INFINITY : a * gain; // linear.c:127: isnan(gain) || amplitude * gain > headroom
-        bool const attack = t > d.headroom;
-        bool const hanging = hang > 0;
-        float const rec = gain * d.recovery_rate;
-        gain = attack ? g : (hanging ? gain : rec);
-        int const hm = hang - 1;
-        hang = attack ? H : (hm > 0 ? hm : 0);
-        // the sample's gain stays with the lane that owns the sample (a lane write: a select on `lane == l` would keep
-        // 64 loop-invariant lane masks alive in scalar registers)
-        int const sg = __builtin_amdgcn_readfirstlane(__float_as_int(gain));
-        asm volatile("v_writelane_b32 %0, %1, %2" : "+v"(gn_j) : "s"(sg), "n"(l));
-      };
-      int const full_rows = olen / 64, tail = olen % 64; // every shape in use has tail == 0
-      static_for<K>([&](auto jc) { // (static row index: a run-time one would turn gn[j] into a chain of selects)
-        constexpr int j = decltype(jc)::value;
-        if (j < full_rows) { // uniform
-          static_for<64>([&](auto lc) {
-            agc_step(gn[j], amp[j], gatt[j], lc);
-            // (the lane reads do not depend on the chain: left alone, the scheduler hoists all of them to the top)
-            if constexpr ((decltype(lc)::value & 7) == 7) __builtin_amdgcn_sched_barrier(0);
-          });
-        } else if (j == full_rows && tail) {
-          static_for<64>([&](auto lc) {
-            if (decltype(lc)::value < tail) agc_step(gn[j], amp[j], gatt[j], lc);
-          });
-        }
-      });
-    }
-    // ---- step 3: linear.c:137-148
+  };
+  // linear.c:137-148 for block b with per-sample gains gn, then the block's status
+  auto store_block = [&](int b, float2 const (&sm)[K], float const (&amp)[K], float const (&gn)[K], float energy_sum, float gain_after) {
+    float2 *yb = y + (size_t)b * olen;
     float level = 0.f;
 #pragma unroll
     for (int j = 0; j < K; j++) {
@@ -1091,11 +1061,10 @@ __global__ __launch_bounds__(64) void kh_demod_linear_w(float2 *__restrict__ bas
         reinterpret_cast<short2 *>(po)[o] = make_short2(pcm_word(w.x, big_endian), pcm_word(w.y, big_endian));
       }
     }
-    energy = wave_sum(energy);
     level = wave_sum(level);
     if (lane == 0) {
       kh_status r;
-      r.bb_power = energy / olen;
+      r.bb_power = energy_sum / olen;
       r.snr = s.snr;
       r.foffset = 0.f;
       r.pdeviation = 0.f;
@@ -1103,26 +1072,202 @@ __global__ __launch_bounds__(64) void kh_demod_linear_w(float2 *__restrict__ bas
       r.lock_timer = 0.f;
       r.pll_lock = s.pll_lock;
       r.output_level = level / (olen * d.channels);
-      r.agc_gain = gain;
+      r.agc_gain = gain_after;
       r.squelch_open = 0;
       r.reserved[0] = r.reserved[1] = 0.f;
       status[(size_t)ch * status_stride + b] = r;
     }
-  }
-  if (lane == 0) {
-    size_t const total = (size_t)nblocks * olen;
-    if (shift_active) {
-      double sn, cs;
-      double ph = phase0 + d.shift_freq * (double)total;
-      ph -= rint(ph);
-      sincospi(2.0 * ph, &sn, &cs);
-      s.shift_re = cs;
-      s.shift_im = sn;
+  };
+
+  // ---- phase 1
+  for (int b = wave; b < nblocks; b += LW_WAVES) {
+    float2 sm[K];
+    float amp[K], energy;
+    load_block(b, sm, amp, energy);
+    float mx = 0.f;
+#pragma unroll
+    for (int j = 0; j < K; j++)
+      if (lane + 64 * j < olen) mx = fmaxf(mx, amp[j]); // (fmaxf drops a NaN amplitude, and a NaN never trips the test either)
+    mx = wave_max(mx);
+    energy = wave_sum(energy);
+    if (lane == 0) {
+      sh_max[b] = mx;
+      sh_energy[b] = energy;
     }
-    s.shift_steps = (int)((s.shift_steps + total) % 16384); // Renorm_rate, osc.c:11
-    s.agc_gain = gain;
-    s.hangcount = hang;
-    states[ch] = s;
+  }
+  __syncthreads();
+
+  // ---- phase 2
+  if (wave == 0) {
+    float gain = s.agc_gain;
+    int hang = s.hangcount;
+    for (int b = 0; b < nblocks; b++) {
+      bool quiet = !d.agc;
+      if (d.agc && hang >= olen && gain >= 0.f) { // (a NaN gain fails the comparison: linear.c:127 attacks at once)
+        float const t = sh_max[b] * gain;
+        quiet = !(t > headroom);
+        if (quiet) hang -= olen;
+      }
+      if (quiet) {
+        if (lane == 0) {
+          sh_gain[b] = gain;
+          sh_done[b] = 0;
+        }
+        continue;
+      }
+      // the block in detail: linear.c:127-136 by EVENTS instead of by samples.  From the state (gain, hang) at some sample
+      // every later lane can work out, on the assumption that nothing attacks before it, the gain it would be tested
+      // against (the iterated fp32 products G_0 = gain, G_{k+1} = fl(G_k * rate), exactly the reference's sequence of
+      // roundings) and the gain it would leave.  The first sample whose test fires is a real attack (everything before it
+      // held its assumption); it sets gain = headroom / amplitude and hang = hangtime, and the search goes on behind it.
+      float2 sm[K];
+      float amp[K], gatt[K], gn[K], energy;
+      load_block(b, sm, amp, energy);
+#pragma unroll
+      for (int j = 0; j < K; j++) {
+        gatt[j] = headroom / amp[j];
+        gn[j] = gain;
+      }
+      constexpr int AGC_MAX_EVENTS = 6;
+      // one pass over row j from lane p: returns the lane to go on from (nvalid when the row is done)
+      auto agc_row_pass = [&](float &gn_j, float amp_j, float gatt_j, int p, int nvalid) -> int {
+        int const rel = lane - p;    // samples since p
+        int const k = rel - hang;    // >= 0: this lane is k samples into the recovery
+        int M = nvalid - p - hang;   // samples of this pass that recover
+        M = M < 0 ? 0 : M;
+        float P = gain, Q = gain, G = gain; // tested against / left with, without an attack before this lane
+        if (M > 0) { // one dependent multiply per sample, in one lane; every lane then picks its two products
+          if (lane == 0) {
+            float g = gain;
+#pragma unroll
+            for (int m = 0; m < 65; m++) {
+              gtab[m] = g;
+              g = g * rate;
+            }
+          }
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+          __builtin_amdgcn_wave_barrier();
+          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+          int const kk = k < 0 ? 0 : (k > 63 ? 63 : k);
+          float const g0 = gtab[kk], g1 = gtab[kk + 1];
+          P = k >= 0 ? g0 : gain;
+          Q = k >= 0 ? g1 : gain;
+          G = gtab[M];
+          __builtin_amdgcn_wave_barrier();
+        }
+        float const t = isnan(P) ? INFINITY : amp_j * P; // linear.c:127: isnan(gain) || amplitude * gain > headroom
+        bool const live = rel >= 0 && lane < nvalid;
+        unsigned long long const fired = __builtin_amdgcn_ballot_w64(live && t > headroom);
+        if (fired == 0) {
+          if (live) gn_j = Q;
+          gain = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(G)));
+          int const left = hang - (nvalid - p);
+          hang = left > 0 ? left : 0;
+          return nvalid;
+        }
+        int const a = __builtin_ctzll(fired);
+        if (live && lane < a) gn_j = Q;
+        if (lane == a) gn_j = gatt_j;
+        gain = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(gatt_j), a));
+        hang = H;
+        return a + 1;
+      };
+      auto agc_row_serial = [&](float &gn_j, float amp_j, float gatt_j, int p, int nvalid) { // the reference's loop
+        for (int l = p; l < nvalid; l++) {
+          float const a = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(amp_j), l));
+          float const g = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(gatt_j), l));
+          float const t = isnan(gain) ? INFINITY : a * gain;
+          if (t > headroom) {
+            gain = g;
+            hang = H;
+          } else if (hang > 0) {
+            hang--;
+          } else {
+            gain = gain * rate;
+          }
+          if (lane == l) gn_j = gain;
+        }
+      };
+      int pos = 0, row_events = 0; // position in the block; passes spent on the current row
+      while (pos < olen) {         // uniform
+        if (hang >= olen - pos) {  // the hang counter outlasts the block: constant gain, one pass over all that is left
+          float const tg = gain;
+          int first = olen;
+          static_for<K>([&](auto jc) {
+            constexpr int jj = decltype(jc)::value;
+            int const n = lane + 64 * jj;
+            float const t = isnan(tg) ? INFINITY : amp[jj] * tg;
+            unsigned long long const f = __builtin_amdgcn_ballot_w64(n >= pos && n < olen && t > headroom);
+            if (f != 0 && first == olen) first = 64 * jj + __builtin_ctzll(f);
+          });
+          float gnew = tg;
+          static_for<K>([&](auto jc) {
+            constexpr int jj = decltype(jc)::value;
+            int const n = lane + 64 * jj;
+            if (n >= pos && n < first && n < olen) gn[jj] = tg;
+            if (n == first) gn[jj] = gatt[jj];
+            if ((first >> 6) == jj) gnew = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(gatt[jj]), first & 63));
+          });
+          if (first == olen) {
+            hang -= olen - pos;
+            pos = olen;
+          } else {
+            gain = gnew;
+            hang = H;
+            pos = first + 1;
+            row_events = 0;
+          }
+          continue;
+        }
+        int const row = pos >> 6, p = pos & 63;
+        int const nvalid = (olen - 64 * row) < 64 ? (olen - 64 * row) : 64;
+        int np = p;
+        bool const serial = ++row_events > AGC_MAX_EVENTS;
+        static_for<K>([&](auto jc) {
+          constexpr int jj = decltype(jc)::value;
+          if (row == jj) { // uniform
+            if (serial) {
+              agc_row_serial(gn[jj], amp[jj], gatt[jj], p, nvalid);
+              np = nvalid;
+            } else {
+              np = agc_row_pass(gn[jj], amp[jj], gatt[jj], p, nvalid);
+            }
+          }
+        });
+        pos = 64 * row + np;
+        if (np >= nvalid) row_events = 0;
+      }
+      store_block(b, sm, amp, gn, sh_energy[b], gain);
+      if (lane == 0) sh_done[b] = 1;
+    }
+    if (lane == 0) {
+      size_t const total = (size_t)nblocks * olen;
+      if (shift_active) {
+        double sn, cs;
+        double ph = phase0 + d.shift_freq * (double)total;
+        ph -= rint(ph);
+        sincospi(2.0 * ph, &sn, &cs);
+        s.shift_re = cs;
+        s.shift_im = sn;
+      }
+      s.shift_steps = (int)((s.shift_steps + total) % 16384); // Renorm_rate, osc.c:11
+      s.agc_gain = gain;
+      s.hangcount = hang;
+      states[ch] = s;
+    }
+  }
+  __syncthreads();
+
+  // ---- phase 3
+  for (int b = wave; b < nblocks; b += LW_WAVES) {
+    if (sh_done[b]) continue; // uniform
+    float const g = sh_gain[b];
+    float2 sm[K];
+    float amp[K], gn[K], energy;
+    load_block(b, sm, amp, energy);
+#pragma unroll
+    for (int j = 0; j < K; j++) gn[j] = g;
+    store_block(b, sm, amp, gn, sh_energy[b], g);
   }
 }
 
@@ -1285,13 +1430,13 @@ int launch_demod(hipStream_t st, float2 *baseband, size_t bb_stride, int olen, i
     else
       hipLaunchKernelGGL(kh_fm_finish_w<16>, grid, dim3(256), 0, st, F, npairs, nfin, Z);
   }
-  // the first n_lin_nopll entries of lin_list have opt.pll off: one wavefront each (kh_demod_linear_w); the others keep
+  // the first n_lin_nopll entries of lin_list have opt.pll off: one workgroup each (kh_demod_linear_w); the others keep
   // the lane-per-channel loop.  KA9Q_HIP_LINEAR_WAVE=0 sends every linear channel there (A/B switch).
   static int const lin_wave_env = getenv("KA9Q_HIP_LINEAR_WAVE") ? atoi(getenv("KA9Q_HIP_LINEAR_WAVE")) : 1;
-  int const nw = (lin_wave_env && olen <= 1024) ? (n_lin_nopll < n_lin ? n_lin_nopll : n_lin) : 0;
+  int const nw = (lin_wave_env && olen <= 1024 && nblocks <= LW_MAXB) ? (n_lin_nopll < n_lin ? n_lin_nopll : n_lin) : 0;
   if (nw > 0) {
     auto const kern = olen <= 256 ? kh_demod_linear_w<4> : olen <= 512 ? kh_demod_linear_w<8> : kh_demod_linear_w<16>;
-    hipLaunchKernelGGL(kern, dim3(nw), dim3(64), 0, st, baseband, bb_stride, olen, nblocks, desc, state, audio, pcm, pcm_stride,
+    hipLaunchKernelGGL(kern, dim3(nw), dim3(64 * LW_WAVES), 0, st, baseband, bb_stride, olen, nblocks, desc, state, audio, pcm, pcm_stride,
                        pcm_big_endian, stt, status_stride, lin_list);
   }
   if (n_lin - nw > 0)

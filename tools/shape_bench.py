@@ -25,6 +25,10 @@ for c in range(C):
     kw = dict(input=c % P, rotate=(2 * (c // P)) if P == 1 else 0, low=-0.17 * out_rate, high=0.17 * out_rate, kaiser_beta=3.0)
     if demod == "fm":
         bank.set_channel(c, demod=pyka9q.KH_DEMOD_FM, **kw)
+    elif demod in ("usb", "usbnoagc", "usbshort"):  # no PLL: the wave-per-channel kernel; usbshort: a hang time of 100 samples
+        bank.set_channel(c, demod=pyka9q.KH_DEMOD_LINEAR, pll=0, agc=int(demod != "usbnoagc"),
+                         hangtime=100.0 if demod == "usbshort" else 1.1 * out_rate, recovery_rate=10 ** ((6.0 / out_rate) / 20),
+                         agc_gain=1e4, **kw)
     elif demod == "linear":
         bank.set_channel(c, demod=pyka9q.KH_DEMOD_LINEAR, pll=1, agc=1, hangtime=1.1 * out_rate, recovery_rate=1.00001, agc_gain=100.0, **kw)
     else:
