@@ -132,3 +132,61 @@ def test_linear_and_am_bank(hip):
                     dphi = abs(st["cphase"] - sig["cphase"])
                     assert min(dphi, 2 * np.pi - dphi) < 1e-4, (name, b, st["cphase"], sig["cphase"])
     bank.close()
+
+
+def test_agc_regimes(hip):
+    """The hang AGC of linear.c:127-136 through every route kh_demod_linear_w takes: blocks the hang counter outlasts (the
+    noted-gain route), recovery with the iterated products, an attack on every sample of a rising envelope (more events per
+    row than AGC_MAX_EVENTS: the sample-by-sample route), a fall of 40 dB (long recovery), a start from a NaN gain, hang
+    times 0 / 37 / 700 samples and 1.1 s, mono and stereo, over three launches.  Bars of test_linear_and_am_bank; a block
+    outside them must be a branch tie (tools/fuzz_linear.is_agc_tie: the first divergence is exactly one recovery step)."""
+    import sys
+    tools = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools")
+    if tools not in sys.path:
+        sys.path.insert(0, tools)
+    from fuzz_linear import is_agc_tie
+    T, calls = 3, 3
+    n = T * calls * L
+    t = np.arange(n) / FS
+    # envelope: steady, rising 0.2 % per output sample (0.05 % per input sample) for two blocks, steady, down 40 dB, steady
+    env = np.ones(n)
+    seg = 2 * L
+    env[2 * L:2 * L + seg] = 1.0005 ** np.arange(seg)
+    env[2 * L + seg:6 * L] = env[2 * L + seg - 1]
+    env[6 * L:] = env[6 * L - 1] * 0.01
+    x = (synth.noise(n, 1e-5, 5) + 0.002 * env * (np.exp(2j * np.pi * 700 * t) + 0.7 * np.exp(2j * np.pi * 1900 * t))).astype(np.complex64)
+    fast = 10 ** ((40.0 / 48000) / 20)
+    cases = [dict(hangtime=0.0, recovery_rate=fast, agc_gain=AGC0, channels=1),
+             dict(hangtime=37.0, recovery_rate=fast, agc_gain=float("nan"), channels=1),
+             dict(hangtime=700.0, recovery_rate=fast, agc_gain=1.0, channels=2),
+             dict(hangtime=1.1 * 48000, recovery_rate=RECOVERY, agc_gain=AGC0, channels=1),
+             dict(hangtime=0.0, recovery_rate=10 ** ((400.0 / 48000) / 20), agc_gain=AGC0, channels=1, env=1)]
+    bank = hip.Bank(L, M, D, 1, len(cases), T, FS)
+    pipe = pipeline.Pipeline(L, M, D, FS)
+    for c, kw in enumerate(cases):
+        kw = dict(kw, low=100.0, high=3000.0, agc=1, headroom=HEADROOM)
+        bank.set_channel(c, demod=hip.KH_DEMOD_LINEAR, **kw)
+        pipe.add_channel(demod="linear", **kw)
+    ties = 0
+    for call in range(calls):
+        bank.write_input(0, x[call * T * L:(call + 1) * T * L])
+        bank.execute(T)
+        for b in range(T):
+            lo = (call * T + b) * L
+            outs, _ = pipe.run_block([x[lo:lo + L]])
+            for c, kw in enumerate(cases):
+                _y, audio, sig = outs[c]
+                nch = 1 if kw.get("env") else kw["channels"]
+                ga = bank.audio(c, T)[b * OLEN * nch:(b + 1) * OLEN * nch]
+                if call == 0 and b == 0:  # (start-up on amplified round-off: see test_linear_and_am_bank)
+                    ga, audio = ga[600 * nch:], audio[600 * nch:]
+                scale = max(float(np.abs(audio).max()), 1e-6)
+                err = float(np.abs(ga - audio).max()) / scale
+                if err > 2e-4:
+                    assert is_agc_tie(ga, audio, kw["recovery_rate"], kw["hangtime"], nch), (c, call, b, err)
+                    ties += 1
+                    continue
+                st = bank.status(c, T)[b]
+                assert abs(st["agc_gain"] - sig["agc_gain"]) <= 1e-4 * abs(sig["agc_gain"]), (c, call, b, st["agc_gain"], sig["agc_gain"])
+    assert ties <= 6
+    bank.close()
