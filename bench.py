@@ -474,7 +474,8 @@ def main():
         dom = max((k for k in stages if k != "carry" and k not in empty), key=lambda k: stages[k]["ms"])
         traffic = traffic_src = None  # HBM bytes per launch of that kernel from the committed PMC passes (profiles/, tools/summarize_prof.py)
         try:
-            cands = sorted(glob.glob(os.path.join(ROOT, "profiles", "r0[2-9]_*hbm_traffic.json"))) or \
+            # (r0N_stepM_hbm_traffic.json: this command; the other r0N_* files are other shapes or switches)
+            cands = sorted(glob.glob(os.path.join(ROOT, "profiles", "r0[2-9]_step[0-9]_hbm_traffic.json"))) or \
                 sorted(glob.glob(os.path.join(ROOT, "profiles", "r01_step8_hbm_traffic.json")))
             prof = json.load(open(cands[-1]))["kernels"]
             key = {"fft1": "kh_fft_cols", "fft2": "kh_fft_rows", "chan": "kh_back_a", "demod": "kh_fm_finish_w", "n0": "kh_n0_pass1"}.get(dom)
