@@ -7,13 +7,12 @@ import bench, torch, pyka9q
 torch.cuda.set_device(0)
 dev = torch.device("cuda", 0)
 assert pyka9q.lib().ka9q_hip_init(0) == 0
-plan, rots = bench.channel_plan(0)
-x = bench.make_input_torch(plan, dev); torch.cuda.synchronize()
-T, L, M, D, C, FS = bench.T, bench.L, bench.M, bench.D, bench.C, bench.FS
-bank = pyka9q.Bank(L, M, D, 1, C, T, FS, payload=pyka9q.KH_PT_CF32, compute_n0=1, n0_low=-5500.0, n0_high=5500.0)
+import workloads
+plan = workloads.config2_plan(64)
+x = bench.make_wideband_torch(bench.SH, plan, bench.T * bench.L, dev); torch.cuda.synchronize()
+T, L = bench.T, bench.L
+bank = bench.build_bank(pyka9q, bench.SH, plan, T)
 bank.keep_audio(0); bank.keep_baseband(0)
-for c, r in enumerate(rots):
-    bank.set_channel(c, demod=pyka9q.KH_DEMOD_FM, rotate=r, low=-5500.0, high=5500.0, kaiser_beta=3.0)
 bank.write_input_device(0, x.data_ptr(), T * L)
 def step():
     bank.commit_input(0, T * L); bank.execute(T, sync=False)
