@@ -971,8 +971,8 @@ __global__ __launch_bounds__(64) void kh_demod_linear(float2 *__restrict__ baseb
 //   phase 2  wavefront 0 walks the blocks in order with the state (gain, hang).  A block that the hang counter outlasts
 //            and whose largest amplitude does not trip the attack test (fl(a * gain) is monotonic in a for gain >= 0, so
 //            then no sample does) leaves the gain alone: note the gain, count the hang down, next block -- a dozen
-//            instructions.  Any other block is worked through on the spot, from attack to attack (agc_row_pass), with the
-//            reference's roundings, and its output written;
+//            instructions.  Any other block is worked through on the spot, from attack to attack, with the reference's
+//            roundings, and its output written;
 //   phase 3  all wavefronts: the blocks that phase 2 only noted get their output, sample x (one constant) gain.
 // algorithmic bytes per (channel, block): 8 olen read + (2 or 4) olen PCM (+ 8 olen baseband rewritten for stereo,
 // linear.c:145); the second read of phase 3 comes from L2.
@@ -988,7 +988,7 @@ __device__ __forceinline__ float wave_max(float v) {
   for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
   return v;
 }
-constexpr int LW_WAVES = 8;      // wavefronts per channel
+constexpr int LW_WAVES = 16;     // wavefronts per channel
 constexpr int LW_MAXB = N0_MAXB; // blocks per launch (LDS notes per block)
 template <int K>
 __global__ __launch_bounds__(64 * LW_WAVES) void kh_demod_linear_w(float2 *__restrict__ baseband, size_t bb_stride, int olen,
@@ -999,7 +999,7 @@ __global__ __launch_bounds__(64 * LW_WAVES) void kh_demod_linear_w(float2 *__res
                                                                    const int *__restrict__ list) {
   __shared__ float sh_max[LW_MAXB], sh_energy[LW_MAXB], sh_gain[LW_MAXB];
   __shared__ unsigned char sh_done[LW_MAXB]; // 1: phase 2 has written the block itself
-  __shared__ float gtab[66];                                              // recovery products of one row (wavefront 0)
+  __shared__ __attribute__((aligned(16))) float gtab[64 * K + 8];                                   // recovery products of one block (wavefront 0)
   int const lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   int const ch = list[blockIdx.x];
   DemodDesc const d = descs[ch];
@@ -1129,49 +1129,6 @@ __global__ __launch_bounds__(64 * LW_WAVES) void kh_demod_linear_w(float2 *__res
         gn[j] = gain;
       }
       constexpr int AGC_MAX_EVENTS = 6;
-      // one pass over row j from lane p: returns the lane to go on from (nvalid when the row is done)
-      auto agc_row_pass = [&](float &gn_j, float amp_j, float gatt_j, int p, int nvalid) -> int {
-        int const rel = lane - p;    // samples since p
-        int const k = rel - hang;    // >= 0: this lane is k samples into the recovery
-        int M = nvalid - p - hang;   // samples of this pass that recover
-        M = M < 0 ? 0 : M;
-        float P = gain, Q = gain, G = gain; // tested against / left with, without an attack before this lane
-        if (M > 0) { // one dependent multiply per sample, in one lane; every lane then picks its two products
-          if (lane == 0) {
-            float g = gain;
-#pragma unroll
-            for (int m = 0; m < 65; m++) {
-              gtab[m] = g;
-              g = g * rate;
-            }
-          }
-          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-          __builtin_amdgcn_wave_barrier();
-          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-          int const kk = k < 0 ? 0 : (k > 63 ? 63 : k);
-          float const g0 = gtab[kk], g1 = gtab[kk + 1];
-          P = k >= 0 ? g0 : gain;
-          Q = k >= 0 ? g1 : gain;
-          G = gtab[M];
-          __builtin_amdgcn_wave_barrier();
-        }
-        float const t = isnan(P) ? INFINITY : amp_j * P; // linear.c:127: isnan(gain) || amplitude * gain > headroom
-        bool const live = rel >= 0 && lane < nvalid;
-        unsigned long long const fired = __builtin_amdgcn_ballot_w64(live && t > headroom);
-        if (fired == 0) {
-          if (live) gn_j = Q;
-          gain = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(G)));
-          int const left = hang - (nvalid - p);
-          hang = left > 0 ? left : 0;
-          return nvalid;
-        }
-        int const a = __builtin_ctzll(fired);
-        if (live && lane < a) gn_j = Q;
-        if (lane == a) gn_j = gatt_j;
-        gain = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(gatt_j), a));
-        hang = H;
-        return a + 1;
-      };
       auto agc_row_serial = [&](float &gn_j, float amp_j, float gatt_j, int p, int nvalid) { // the reference's loop
         for (int l = p; l < nvalid; l++) {
           float const a = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(amp_j), l));
@@ -1188,54 +1145,76 @@ __global__ __launch_bounds__(64 * LW_WAVES) void kh_demod_linear_w(float2 *__res
           if (lane == l) gn_j = gain;
         }
       };
-      int pos = 0, row_events = 0; // position in the block; passes spent on the current row
-      while (pos < olen) {         // uniform
-        if (hang >= olen - pos) {  // the hang counter outlasts the block: constant gain, one pass over all that is left
-          float const tg = gain;
-          int first = olen;
+      int pos = 0, events = 0; // position in the block; passes spent on it
+      while (pos < olen) {     // uniform
+        if (++events > AGC_MAX_EVENTS) { // attacks come thick: the rest of the block sample by sample
           static_for<K>([&](auto jc) {
             constexpr int jj = decltype(jc)::value;
-            int const n = lane + 64 * jj;
-            float const t = isnan(tg) ? INFINITY : amp[jj] * tg;
-            unsigned long long const f = __builtin_amdgcn_ballot_w64(n >= pos && n < olen && t > headroom);
-            if (f != 0 && first == olen) first = 64 * jj + __builtin_ctzll(f);
+            int const lo = 64 * jj, hi = (olen - lo) < 64 ? (olen - lo) : 64;
+            if (pos < lo + hi && hi > 0) agc_row_serial(gn[jj], amp[jj], gatt[jj], pos > lo ? pos - lo : 0, hi);
           });
-          float gnew = tg;
-          static_for<K>([&](auto jc) {
-            constexpr int jj = decltype(jc)::value;
-            int const n = lane + 64 * jj;
-            if (n >= pos && n < first && n < olen) gn[jj] = tg;
-            if (n == first) gn[jj] = gatt[jj];
-            if ((first >> 6) == jj) gnew = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(gatt[jj]), first & 63));
-          });
-          if (first == olen) {
-            hang -= olen - pos;
-            pos = olen;
-          } else {
-            gain = gnew;
-            hang = H;
-            pos = first + 1;
-            row_events = 0;
-          }
-          continue;
+          pos = olen;
+          break;
         }
-        int const row = pos >> 6, p = pos & 63;
-        int const nvalid = (olen - 64 * row) < 64 ? (olen - 64 * row) : 64;
-        int np = p;
-        bool const serial = ++row_events > AGC_MAX_EVENTS;
-        static_for<K>([&](auto jc) {
-          constexpr int jj = decltype(jc)::value;
-          if (row == jj) { // uniform
-            if (serial) {
-              agc_row_serial(gn[jj], amp[jj], gatt[jj], p, nvalid);
-              np = nvalid;
-            } else {
-              np = agc_row_pass(gn[jj], amp[jj], gatt[jj], p, nvalid);
+        // one pass over all that is left of the block: sample n >= pos is k = n - pos - hang samples into the recovery
+        // (k < 0: still hanging); the recovery products are laid out once, by one lane, one dependent multiply each
+        int M = olen - pos - hang;
+        M = M < 0 ? 0 : M;
+        if (M > 0) {
+          if (lane == 0) { // (16-byte LDS writes: a write per product doubled the cost of a step of the chain)
+            float g = gain;
+            for (int m = 0; m <= M; m += 8) { // the table has room for the overshoot (64 K + 8 entries)
+              float4 a, c4;
+              a.x = g, g = g * rate;
+              a.y = g, g = g * rate;
+              a.z = g, g = g * rate;
+              a.w = g, g = g * rate;
+              c4.x = g, g = g * rate;
+              c4.y = g, g = g * rate;
+              c4.z = g, g = g * rate;
+              c4.w = g, g = g * rate;
+              *reinterpret_cast<float4 *>(gtab + m) = a;
+              *reinterpret_cast<float4 *>(gtab + m + 4) = c4;
             }
           }
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+          __builtin_amdgcn_wave_barrier();
+          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        }
+        float const tg = gain;
+        float Q[K];
+        int first = olen;
+        static_for<K>([&](auto jc) {
+          constexpr int jj = decltype(jc)::value;
+          int const n = lane + 64 * jj;
+          int const k = n - pos - hang;
+          bool const rec = M > 0 && k >= 0 && n < olen;
+          int const kk = rec ? k : 0;
+          float const P = rec ? gtab[kk] : tg;
+          Q[jj] = rec ? gtab[kk + 1] : tg;
+          float const t = isnan(P) ? INFINITY : amp[jj] * P; // linear.c:127: isnan(gain) || amplitude * gain > headroom
+          unsigned long long const f = __builtin_amdgcn_ballot_w64(n >= pos && n < olen && t > headroom);
+          if (f != 0 && first == olen) first = 64 * jj + __builtin_ctzll(f);
         });
-        pos = 64 * row + np;
-        if (np >= nvalid) row_events = 0;
+        float gnew = tg;
+        static_for<K>([&](auto jc) {
+          constexpr int jj = decltype(jc)::value;
+          int const n = lane + 64 * jj;
+          if (n >= pos && n < first && n < olen) gn[jj] = Q[jj];
+          if (n == first) gn[jj] = gatt[jj];
+          if ((first >> 6) == jj) gnew = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(gatt[jj]), first & 63));
+        });
+        if (first == olen) {
+          if (M > 0) gain = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(gtab[M])));
+          int const left = hang - (olen - pos);
+          hang = left > 0 ? left : 0;
+          pos = olen;
+        } else {
+          gain = gnew;
+          hang = H;
+          pos = first + 1;
+        }
+        __builtin_amdgcn_wave_barrier(); // (the table is rewritten by the next pass)
       }
       store_block(b, sm, amp, gn, sh_energy[b], gain);
       if (lane == 0) sh_done[b] = 1;
