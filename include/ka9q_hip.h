@@ -285,6 +285,15 @@ struct kh_rtp_state {   /* demod->output.rtp.{timestamp,seq,packets,bytes}, outp
   uint16_t silent;
   uint64_t packets, bytes, samples;
 };
+/* The demodulator state of one channel -- what the reference keeps in its demod thread's locals and in struct demod
+ * between blocks (fm.c:26-33 state/lastaudio/squelch; linear.c:29-44 AGC gain, hang count, PLL integrator, VCO phasor
+ * and frequency, lock count, shift oscillator; am.c:26-35) -- as an opaque record of kh_bank_channel_state_size() bytes,
+ * valid between launches.  A channel moves to another bank (another GPU's process fed by the same stream) by
+ * kh_bank_set_channel there with the same parameters, then kh_bank_set_channel_state: its next block continues where the
+ * last one here ended.  Both synchronise.  The RTP counters travel separately (kh_bank_rtp_set_state). */
+size_t kh_bank_channel_state_size(void);
+int kh_bank_get_channel_state(kh_bank *, unsigned int ch, void *out, size_t bytes);
+int kh_bank_set_channel_state(kh_bank *, unsigned int ch, const void *in, size_t bytes);
 int kh_bank_rtp_enable(kh_bank *, int enable);                                   /* default 0 */
 int kh_bank_rtp_set_state(kh_bank *, unsigned int ch, const struct kh_rtp_state *);
 /* chunks of the last execute for channel ch, in order; *nchunks = nblocks * ceil(olen*channels/480) (0 for a channel

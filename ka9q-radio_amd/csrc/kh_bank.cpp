@@ -445,6 +445,43 @@ int kh_bank_set_channel(kh_bank *b, unsigned int ch, const struct kh_channel_con
   return 0;
 }
 
+// ---- demodulator state of a channel as an opaque record (moving a channel to another bank / another GPU's process)
+size_t kh_bank_channel_state_size(void) { return sizeof(DemodState); }
+int kh_bank_get_channel_state(kh_bank *b, unsigned int ch, void *out, size_t bytes) {
+  if (!b || ch >= (unsigned)b->C || !out || bytes != sizeof(DemodState)) {
+    set_error("kh_bank_get_channel_state: bad channel, or the buffer is not kh_bank_channel_state_size() bytes");
+    return -1;
+  }
+  DemodState s;
+  if (kh_bank_sync(b)) return -1; // (the launches in flight)
+  if (!KH_HIP(hipMemcpyAsync(&s, b->d_dstate + ch, sizeof(s), hipMemcpyDeviceToHost, b->stream)) ||
+      !KH_HIP(hipStreamSynchronize(b->stream)))
+    return -1;
+  if (b->fm_parity) { // the record holds the FM state the NEXT launch reads in slot 0, whatever this bank's parity is
+    std::swap(s.fm_state[0], s.fm_state[1]);
+    std::swap(s.fm_lastaudio[0], s.fm_lastaudio[1]);
+    std::swap(s.fm_squelch_open[0], s.fm_squelch_open[1]);
+  }
+  memcpy(out, &s, sizeof(s));
+  return 0;
+}
+int kh_bank_set_channel_state(kh_bank *b, unsigned int ch, const void *in, size_t bytes) {
+  if (!b || ch >= (unsigned)b->C || !in || bytes != sizeof(DemodState)) {
+    set_error("kh_bank_set_channel_state: bad channel, or the buffer is not kh_bank_channel_state_size() bytes");
+    return -1;
+  }
+  if (kh_bank_sync(b)) return -1;
+  DemodState s;
+  memcpy(&s, in, sizeof(s));
+  // both slots: the next launch reads slot fm_parity, and nothing reads the other before that launch has rewritten it
+  s.fm_state[1] = s.fm_state[0];
+  s.fm_lastaudio[1] = s.fm_lastaudio[0];
+  s.fm_squelch_open[1] = s.fm_squelch_open[0];
+  hipStream_t st = b->stream;
+  if (!KH_HIP(hipMemcpyAsync(b->d_dstate + ch, &s, sizeof(s), hipMemcpyHostToDevice, st))) return -1;
+  return KH_HIP(hipStreamSynchronize(st)) ? 0 : -1;
+}
+
 int kh_bank_set_lo(kh_bank *b, unsigned int input, double lo2_freq, double doppler_freq, double doppler_rate) {
   if (!b || input >= (unsigned)b->P) return -1;
   b->lo2[input].set(lo2_freq, 0.0);                    // set_second_LO, radio.c:350

@@ -28,7 +28,7 @@ EXPORTS = [
     "kh_bank_debug_pending", "kh_bank_stream_open", "kh_bank_stream_slot", "kh_bank_stream_submit", "kh_bank_stream_close", "kh_bank_read_pcm_all",
     "kh_bank_execute", "kh_bank_sync", "kh_bank_read_baseband", "kh_bank_read_pcm", "kh_bank_read_audio",
     "kh_bank_read_status", "kh_bank_read_input_status", "kh_bank_read_spectrum", "kh_bank_read_response",
-    "kh_bank_pcm_device_ptr", "kh_bank_keep_audio", "kh_bank_keep_baseband", "kh_bank_use_graph", "kh_bank_stream", "kh_bank_profile", "kh_bank_stage_times",
+    "kh_bank_pcm_device_ptr", "kh_bank_keep_audio", "kh_bank_keep_baseband", "kh_bank_channel_state_size", "kh_bank_get_channel_state", "kh_bank_set_channel_state", "kh_bank_use_graph", "kh_bank_stream", "kh_bank_profile", "kh_bank_stage_times",
     "kh_stage_kernel_name", "kh_bank_rtp_enable", "kh_bank_rtp_set_state", "kh_bank_read_rtp",
     "kh_afsk_create", "kh_afsk_destroy", "kh_afsk_write_pcm", "kh_afsk_pcm_device_ptr", "kh_afsk_commit_pcm",
     "kh_afsk_execute", "kh_afsk_sync", "kh_afsk_read_frames", "kh_afsk_read_bits", "kh_afsk_read_status",
@@ -182,6 +182,10 @@ def lib():
     L.kh_bank_rtp_set_state.argtypes = [C.c_void_p, C.c_uint, C.c_void_p]
     L.kh_bank_read_rtp.argtypes = [C.c_void_p, C.c_uint, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t), C.c_void_p]
     L.kh_bank_keep_baseband.argtypes = [C.c_void_p, C.c_int]
+    L.kh_bank_channel_state_size.argtypes = []
+    L.kh_bank_channel_state_size.restype = C.c_size_t
+    L.kh_bank_get_channel_state.argtypes = [C.c_void_p, C.c_uint, C.c_void_p, C.c_size_t]
+    L.kh_bank_set_channel_state.argtypes = [C.c_void_p, C.c_uint, C.c_void_p, C.c_size_t]
     L.kh_bank_use_graph.argtypes = [C.c_void_p, C.c_int]
     L.kh_bank_stage_times.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_uint)]
     L.kh_stage_kernel_name.restype = C.c_char_p
@@ -466,6 +470,14 @@ class Bank:
 
     def use_graph(self, enable):
         _check(self.lib.kh_bank_use_graph(self.h, int(enable)), "kh_bank_use_graph")
+
+    def get_channel_state(self, ch):
+        buf = C.create_string_buffer(self.lib.kh_bank_channel_state_size())
+        _check(self.lib.kh_bank_get_channel_state(self.h, ch, buf, len(buf)), "kh_bank_get_channel_state")
+        return buf.raw
+
+    def set_channel_state(self, ch, blob):
+        _check(self.lib.kh_bank_set_channel_state(self.h, ch, blob, len(blob)), "kh_bank_set_channel_state")
 
     def keep_baseband(self, enable):
         _check(self.lib.kh_bank_keep_baseband(self.h, int(enable)), "kh_bank_keep_baseband")

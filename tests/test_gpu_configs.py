@@ -419,3 +419,64 @@ def test_compute_n0_modes_agree(hip, monkeypatch, shape):
     for name in ("direct", "fallback"):
         for b, (g, r) in enumerate(zip(results[name], results["reread"])):
             assert abs(g - r) <= 1e-5 * abs(r), (name, b, g, r)
+
+
+@pytest.mark.parametrize("shape", ["192k", "8M"])
+def test_channel_state_moves_between_banks(hip, shape):
+    """kh_bank_get_channel_state / kh_bank_set_channel_state: a channel's demodulator state (fm.c:26-33; linear.c:29-44 AGC, PLL,
+    oscillators) carried to another bank that has been fed the same stream while tuned elsewhere.  After set_channel with the
+    channel's parameters and set_channel_state, the next launch of the second bank equals the first bank's bit for bit --
+    FM (de-emphasised and flat), USB with hang AGC, coherent AM with the PLL; the two banks have run different numbers of
+    launches (different FM state parity)."""
+    if shape == "192k":
+        fs, L, M, D = 192_000, 3840, 4353, 4
+        plan = [dict(demod=hip.KH_DEMOD_FM, k=-1), dict(demod=hip.KH_DEMOD_FM, k=2, flat=1),
+                dict(demod=hip.KH_DEMOD_LINEAR, k=0, agc=1, hangtime=700.0, recovery_rate=10 ** ((20.0 / 48000) / 20), agc_gain=1e4, low=100.0, high=3000.0),
+                dict(demod=hip.KH_DEMOD_LINEAR, k=3, pll=1, agc=1, hangtime=1.1 * 48000, recovery_rate=10 ** ((6.0 / 48000) / 20), agc_gain=1e4)]
+    else:
+        fs, L, M, D = 8_000_000, 131072, 131073, 256
+        plan = [dict(demod=hip.KH_DEMOD_FM, k=-7), dict(demod=hip.KH_DEMOD_FM, k=4, flat=1), dict(demod=hip.KH_DEMOD_FM, k=9)]
+    N = L + M - 1
+    T = 3
+    nblk = 3 * T
+    t = np.arange(nblk * L) / fs
+    x = synth.noise(nblk * L, 0.005, 9).astype(np.complex128)
+    for j, ch in enumerate(plan):
+        f = synth.rotate_for(ch["k"], 12500.0, N, fs) * fs / N
+        if ch["demod"] == hip.KH_DEMOD_FM:
+            x += 0.05 * np.exp(1j * (2 * np.pi * f * t + (2500.0 / (400 + 90 * j)) * np.sin(2 * np.pi * (400 + 90 * j) * t)))
+        else:
+            x += 0.05 * (1 + 0.5 * np.cos(2 * np.pi * 500 * t)) * np.exp(2j * np.pi * (f + 3.0) * t)
+    x = x.astype(np.complex64)
+
+    def tune(bank, c, ch, k):
+        kw = {key: v for key, v in ch.items() if key not in ("demod", "k")}
+        kw.setdefault("low", -5000.0)
+        kw.setdefault("high", 5000.0)
+        bank.set_channel(c, demod=ch["demod"], rotate=synth.rotate_for(k, 12500.0, N, fs), kaiser_beta=3.0, **kw)
+
+    a = hip.Bank(L, M, D, 1, len(plan), T, fs)
+    b = hip.Bank(L, M, D, 1, len(plan), T, fs)
+    for c, ch in enumerate(plan):
+        tune(a, c, ch, ch["k"])
+        tune(b, c, ch, ch["k"] + 5)  # elsewhere on the raster
+    for lo, nb in ((0, T), (T, T)):
+        a.write_input(0, x[lo * L:(lo + nb) * L])
+        a.execute(nb)
+    for lo, nb in ((0, T), (T, 2), (T + 2, 1)):  # the same stream in three launches
+        b.write_input(0, x[lo * L:(lo + nb) * L])
+        b.execute(nb)
+    assert hip.lib().kh_bank_channel_state_size() == len(a.get_channel_state(0))
+    for c, ch in enumerate(plan):
+        tune(b, c, ch, ch["k"])
+        b.set_channel_state(c, a.get_channel_state(c))
+    for bank in (a, b):
+        bank.write_input(0, x[2 * T * L:3 * T * L])
+        bank.execute(T)
+    for c, ch in enumerate(plan):
+        assert np.array_equal(a.pcm(c, T), b.pcm(c, T)), c
+        assert a.status(c, T).tobytes() == b.status(c, T).tobytes(), c
+        assert np.abs(a.pcm(c, T)).max() > 100, c
+        assert a.get_channel_state(c) == b.get_channel_state(c), c  # (the record is normalised: slot 0 is what the next launch reads)
+    a.close()
+    b.close()
