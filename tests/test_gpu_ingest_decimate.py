@@ -271,3 +271,32 @@ def test_fused_cascade_equals_the_staged_one(hip, monkeypatch, logd, thresh, chu
         assert np.array_equal(a[:, chunk:], x[:, chunk:]), chunk  # the fused route leaves the rest of the caller's rails alone
         assert bytes(sa) == bytes(sb), chunk
         assert np.array_equal(ha, hb), chunk
+
+
+def test_decimation_of_device_rails_reads_them_in_place(hip):
+    """kh_decimate_rails with DEVICE pointers (hackrf.c:495-509 when kh_hackrf_correct has left the rails on the GPU): the fused
+    cascade reads the caller's rails where they lie and writes the first `chunk` floats of each back; same floats as the
+    host-pointer call, rail stride larger than the rail, the rest of the buffer untouched, states (host memory) carried."""
+    from test_zz_no_alloc import Dev
+    global hip_Hb15
+    hip_Hb15 = hip.Hb15State
+    rng = np.random.default_rng(77)
+    Lh = hip.lib()
+    rails, logd, thresh = 2, 6, 8
+    stride = (3000 << logd) + 192  # floats between rails: more than any call's rail
+    sa, sb = _f8_states(rails * logd), _f8_states(rails * logd)
+    ha, hb = np.zeros(rails * logd, np.float32), np.zeros(rails * logd, np.float32)
+    for chunk in (480, 3000, 129):
+        n = chunk << logd
+        x = np.zeros((rails, stride), np.float32)
+        x[:, :n] = rng.uniform(-1, 1, (rails, n))
+        x[:, n:] = 7.0  # must survive
+        h = x.copy()
+        assert Lh.kh_decimate_rails(sa, ha.ctypes.data, logd, thresh, h.ctypes.data, stride, rails, chunk) == 0, hip.last_error()
+        d = Dev(x)
+        assert Lh.kh_decimate_rails(sb, hb.ctypes.data, logd, thresh, d.ptr, stride, rails, chunk) == 0, hip.last_error()
+        g = d.get()
+        d.free()
+        assert np.array_equal(g[:, :chunk], h[:, :chunk]), chunk
+        assert np.array_equal(g[:, chunk:], x[:, chunk:]), chunk
+        assert bytes(sa) == bytes(sb) and np.array_equal(ha, hb), chunk

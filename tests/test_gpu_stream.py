@@ -70,3 +70,28 @@ def test_stream_matches_write_input(hip, monkeypatch, payload_name, depth, env):
     st.execute(1)
     for b in banks:
         b.close()
+
+
+def test_stream_api_refuses_what_it_cannot_do(hip):
+    """error behaviour of kh_bank_stream_*: every misuse is a return code and a message, never a launch"""
+    fs, L, M, D = 8_000_000, 131072, 131073, 256
+    b = hip.Bank(L, M, D, 1, 2, 2, fs, payload=hip.KH_PT_IQ16LE)
+    for c in range(2):
+        b.set_channel(c, demod=hip.KH_DEMOD_FM, rotate=2 * c, low=-5500.0, high=5500.0, kaiser_beta=3.0)
+    lib = hip.lib()
+    assert lib.kh_bank_stream_submit(b.h, 1) != 0 and "not open" in hip.last_error()
+    assert not lib.kh_bank_stream_slot(b.h, 0, None)
+    assert lib.kh_bank_stream_open(b.h, 1) != 0 and "depth" in hip.last_error()
+    assert lib.kh_bank_stream_open(b.h, 65) != 0
+    b.stream_open(2)
+    assert lib.kh_bank_stream_open(b.h, 2) != 0 and "already open" in hip.last_error()
+    assert not lib.kh_bank_stream_slot(b.h, 1, None)  # input out of range
+    assert lib.kh_bank_stream_submit(b.h, 0) != 0 and lib.kh_bank_stream_submit(b.h, 3) != 0  # outside [1, max_blocks]
+    # a short launch after the refusals still works, and closing twice is harmless
+    slot = b.stream_slot(0, np.int16, 2 * L)
+    slot[:] = 100
+    b.stream_submit(1)
+    assert b.pcm_all(1).shape[0] == 2
+    b.stream_close()
+    b.stream_close()
+    b.close()
