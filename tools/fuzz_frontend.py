@@ -51,6 +51,40 @@ def tone_iq(rng, n, full_scale):
     return iq
 
 
+def hackrf_rx_f64(iq, samples, nblocks, offset, rate, imb0):
+    """hackrf.c:822-919 in float64 (vectorised per transfer; the state chain from transfer to transfer as in the reference):
+    the yardstick for transfers long enough that the reference's own fp32 running sums (850-870) show."""
+    DC = 0j
+    imbalance, sinphi, gi, gq, sec, tan = imb0, 0.0, 1.0, 1.0, 1.0, 0.0
+    rot = 0
+    oi, oq = np.empty(samples * nblocks), np.empty(samples * nblocks)
+    for b in range(nblocks):
+        seg = iq[2 * b * samples:2 * (b + 1) * samples].astype(np.float64) / 127.0
+        z = np.maximum(seg[0::2], -1.0) + 1j * np.maximum(seg[1::2], -1.0)
+        ssum = z.sum()
+        z = z - DC
+        ie, qe = float((z.real ** 2).sum()), float((z.imag ** 2).sum())
+        re, im = z.real * gi, z.imag * gq
+        dot = float((re * im).sum())
+        im = sec * im - tan * re
+        ph = (rot + offset * np.arange(samples)) & 3
+        sl = slice(b * samples, (b + 1) * samples)
+        oi[sl] = np.choose(ph, [re, -im, -re, im])
+        oq[sl] = np.choose(ph, [im, re, -im, -re])
+        rot = (rot + offset * samples) & 3
+        DC += 0.001 * (ssum / samples - DC)
+        if ie + qe > 0:
+            imbalance += rate * samples * (ie / qe - imbalance)
+            sinphi += rate * samples * (2 * dot / (ie + qe) - sinphi)
+            gq, gi = np.sqrt(0.5 * (1 + imbalance)), np.sqrt(0.5 * (1 + 1.0 / imbalance))
+            sec = 1 / np.sqrt(1 - sinphi * sinphi)
+            tan = sinphi * sec
+    return oi, oq
+
+
+REFEREED = []
+
+
 def hackrf_case(rng):
     samples = int(rng.choice([5, 64, 1000, 4099, 16384, 65536, 131072]))
     nblocks = int(rng.integers(1, 9 if samples <= 16384 else 4))
@@ -71,7 +105,15 @@ def hackrf_case(rng):
     what = f"hackrf samples={samples} blocks={nblocks} offset={offset} imb0={imb0} rate={rate:.1e}"
     bar = 1e-5 if samples <= 16384 else 5e-5
     e = max(rel_rms(gi, oi), rel_rms(gq, oq))
-    assert e < bar, f"{what}: rails {e:.2e}"
+    if not e < bar:
+        # outside the bar against the oracle: judged against float64.  The device takes the transfer's sums from exact
+        # integer moments, the reference adds 131072 fp32 terms one by one; the GPU must be closer to float64 than the
+        # oracle is, and within the short-transfer bar of it
+        fi, fq = hackrf_rx_f64(iq, samples, nblocks, offset, rate, imb0)
+        eg = max(rel_rms(gi, fi.astype(np.float32)), rel_rms(gq, fq.astype(np.float32)))
+        eo = max(rel_rms(oi, fi.astype(np.float32)), rel_rms(oq, fq.astype(np.float32)))
+        assert eg < 1e-5 and eg < eo, f"{what}: rails {e:.2e} (gpu-float64 {eg:.2e}, oracle-float64 {eo:.2e})"
+        REFEREED.append(f"{what}: rails gpu-oracle {e:.2e}, gpu-float64 {eg:.2e}, oracle-float64 {eo:.2e}")
     check_state(st_g, orc.fe_fields(st_o), what, samples)
     return what, e
 
@@ -122,7 +164,10 @@ def main():
             print(f"[{k}] BAD {str(e)[:400]}", flush=True)
     for t in RUNNING_SUM:
         print("state beyond 1e-4 of the oracle (fp32 running sum over >= 65536 samples): %s: %s by %.1e" % t)
-    print(f"{cases} cases, {bad} bad, {len(RUNNING_SUM)} state values off by the reference's running sums, {time.time() - t0:.0f} s")
+    for line in REFEREED:
+        print("rails judged against float64: " + line)
+    print(f"{cases} cases, {bad} bad, {len(RUNNING_SUM)} state values off by the reference's running sums, {len(REFEREED)} rails judged "
+          f"against float64, {time.time() - t0:.0f} s")
     return 1 if bad else 0
 
 

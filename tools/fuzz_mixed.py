@@ -41,6 +41,7 @@ def run_case(rng, ties):
         dem = kw.pop("demod")
         bank.set_channel(c, demod=ids[dem], **kw)
         pipe.add_channel(demod=dem, **kw)
+    hist = []  # the oracle's status records, block by block (for the diagnostics below)
     try:
         for call in range(calls):
             for i, s in enumerate(SIGS):
@@ -52,6 +53,7 @@ def run_case(rng, ties):
             for b in range(T):
                 lo = (call * T + b) * L
                 outs, _ = pipe.run_block([sigs[s][lo:lo + L] for s in SIGS])
+                hist.append([o[2] for o in outs])
                 for c, kw in enumerate(chans):
                     _y, audio, sig = outs[c]
                     what = f"ch {c}/{C} {kw} block {b} call {call}"
@@ -63,7 +65,29 @@ def run_case(rng, ties):
                     d = np.abs(gp.astype(np.int32) - orc.scaleclip(audio).astype(np.int32))
                     st = g_st[c][b]
                     if kw["demod"] == "fm":
-                        assert np.allclose(ga, audio, rtol=1e-4, atol=2e-5), f"{what}: FM audio"
+                        if not np.allclose(ga, audio, rtol=1e-4, atol=2e-5):
+                            e = np.abs(ga - audio) - 1e-4 * np.abs(audio)
+                            i = int(np.argmax(e))
+                            # fm.c:86,123: after a closed block state = 0, and sample 0 of the next open block is
+                            # cargf(y[0] * conjf(0)): a pair of signed zeros, for which atan2f answers 0, -0, pi or -pi by the
+                            # signs of y[0]'s components.  When one component of y[0] is itself zero to rounding (here the two
+                            # sides may hold +-1e-9 of a 0.05 sample) the answer is a coin toss in the reference too.  Verified,
+                            # not assumed: only sample 0 is off, both values are 0 or +-pi*gain, and a component of y[0] is
+                            # below 1e-6 of its magnitude on both sides.
+                            gain_fm = kw["headroom"] / np.pi * (FS / D) / abs(kw["low"] - kw["high"])
+                            y0g, y0o = complex(bank.baseband(c, T)[b * OLEN]), complex(_y[0])
+                            knife = all(min(abs(v.real), abs(v.imag)) <= 1e-6 * abs(v) for v in (y0g, y0o))
+                            quant = all(min(abs(abs(v) - q) for q in (0.0, np.pi * gain_fm)) <= 1e-5 for v in (float(ga[0]), float(audio[0])))
+                            if i == 0 and int((e > 2e-5).sum()) == 1 and kw.get("flat") and knife and quant:
+                                ties.append(f"{what}: signed-zero tie at sample 0 (y[0] gpu {y0g!r} oracle {y0o!r})")
+                                continue
+                            raise AssertionError(f"{what}: FM audio, worst at sample {i} of {ga.size}: gpu "
+                                                 f"{np.array2string(ga[max(i - 2, 0):i + 3], precision=7)} oracle "
+                                                 f"{np.array2string(audio[max(i - 2, 0):i + 3], precision=7)}; snr gpu {st['snr']:.6g} "
+                                                 f"oracle {sig['snr']:.6g}, bb_power {st['bb_power']:.6g} / {sig['bb_power']:.6g}, "
+                                                 f"samples beyond the bar: {int((e > 2e-5).sum())}; y[0] gpu {bank.baseband(c, T)[b * OLEN]!r} oracle {_y[0]!r}; oracle (snr, squelch) of the blocks so far "
+                                                 f"{[(round(float(h[c]['snr']), 3), int(h[c].get('squelch_open', -1))) for h in hist[-4:]]}, gpu "
+                                                 f"{[(round(float(g_st[c][bb]['snr']), 3), int(g_st[c][bb]['squelch_open'])) for bb in range(b + 1)]}")
                         assert d.max() <= 1, f"{what}: FM pcm max diff {d.max()}"
                         for key in ("bb_power", "snr", "output_level"):
                             floor = 1e-4 if key == "snr" else 1e-12
@@ -113,7 +137,7 @@ def main():
             print(f"[{k}] BAD {str(e)[:600]}", flush=True)
     for t in ties:
         print("agc tie:", t)
-    print(f"{cases} cases, {bad} bad, {len(ties)} blocks with an AGC branch tie, {time.time() - t0:.0f} s")
+    print(f"{cases} cases, {bad} bad, {len(ties)} blocks with a verified branch tie (AGC attack, or signed zero at a squelch opening), {time.time() - t0:.0f} s")
     return 1 if bad else 0
 
 
