@@ -988,6 +988,87 @@ __device__ __forceinline__ float wave_max(float v) {
   for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
   return v;
 }
+// The recovery products G_0 = gain, G_{j+1} = fl(G_j * rate) without walking them.  Within a binade a float's bit
+// pattern is linear in its significand m, and the step of the pattern, inc(m) = bits(fl(G rate)) - bits(G), is
+// round(m (rate - 1)) with the significand's ulp as unit: monotonic in m (whatever the tie rule picks lies between its
+// neighbours' results) and nearly constant -- at 6 dB/s and 39 kHz it changes by one every 190..380 steps.  So the
+// products of a block are a handful of RUNS of constant step.  A run from G with step q = inc(G) ends at the first n
+// where the REAL product disagrees, bits(fl((G + n q) rate)) - (G + n q) != q, or where G + n q leaves the binade; both
+// are monotonic in n, so two ballots find n (64 candidates, then the S between two of them), and by the monotonicity
+// every product before it is exactly G + j q: nothing is approximated and nothing is left to check afterwards.  The
+// step out of a binade is taken by the real product.  Per run ~30 instructions instead of one dependent multiply per
+// sample (a lone wavefront issues one every ~13 cycles).
+constexpr int REC_RUNS = 6;
+struct RecRuns {
+  int n;                     // runs in use
+  int start[REC_RUNS];       // first index of the run
+  unsigned bits[REC_RUNS];   // G_start as a bit pattern
+  unsigned inc[REC_RUNS];    // per-step increment of the pattern (two's complement: rate < 1 steps down)
+};
+// runs for G_0 .. G_M (M <= 4096); false: more than REC_RUNS runs, or a gain that is not a positive normal number.
+// Wave-uniform; every lane of the wavefront must be active.
+__device__ __forceinline__ bool rec_build(RecRuns &R, float gain, float rate, int M, int lane) {
+  unsigned b = __float_as_uint(gain);
+  int j0 = 0;
+  bool open = true, good = true;
+  R.n = 0;
+  static_for<REC_RUNS>([&](auto rc) {
+    constexpr int r = decltype(rc)::value;
+    R.start[r] = 0, R.bits[r] = 0, R.inc[r] = 0;
+    if (!open) return; // uniform
+    unsigned const ex = b >> 23;
+    if (ex < 1 || ex > 253) { // zero, denormal, infinite, NaN, negative
+      good = false, open = false;
+      return;
+    }
+    unsigned const q = __float_as_uint(__uint_as_float(b) * rate) - b;
+    R.start[r] = j0, R.bits[r] = b, R.inc[r] = q;
+    R.n = r + 1;
+    int const rem = M - j0;
+    if (rem <= 0) {
+      open = false;
+      return;
+    }
+    auto pred = [&](int n) { // the pattern has left the binade, or the real product steps differently from here
+      unsigned const v = b + (unsigned)n * q;
+      return ((v ^ b) >> 23) != 0 || __float_as_uint(__uint_as_float(v) * rate) - v != q;
+    };
+    int const S = (rem + 63) >> 6;
+    int const n1 = (lane + 1) * S;
+    unsigned long long const fv = __builtin_amdgcn_ballot_w64(n1 <= rem); // the rem / S multiples of S in reach
+    unsigned long long const f1 = __builtin_amdgcn_ballot_w64(n1 <= rem && pred(n1));
+    int const l1 = f1 ? __builtin_ctzll(f1) : __builtin_popcountll(fv); // (none: only the tail behind the last multiple is left)
+    int const lo = l1 * S;                             // pred(lo) is false, or lo = 0
+    int const n2 = lo + 1 + lane;
+    unsigned long long const f2 = __builtin_amdgcn_ballot_w64(lane < S && n2 <= rem && pred(n2));
+    if (f2 == 0) { // the run reaches the end
+      open = false;
+      return;
+    }
+    int const n = lo + 1 + __builtin_ctzll(f2);
+    unsigned const v = b + (unsigned)n * q;
+    if (((v ^ b) >> 23) != 0) // out of the binade: that one step by the real product
+      b = __float_as_uint(__uint_as_float(b + (unsigned)(n - 1) * q) * rate);
+    else
+      b = v;
+    j0 += n;
+  });
+  return good && !open;
+}
+__device__ __forceinline__ unsigned rec_at(RecRuns const &R, int j) { // bit pattern of G_j
+  unsigned base = R.bits[0], q = R.inc[0];
+  int st = 0;
+  static_for<REC_RUNS - 1>([&](auto rc) {
+    constexpr int r = decltype(rc)::value + 1;
+    if (r < R.n) { // uniform
+      bool const in = j >= R.start[r];
+      base = in ? R.bits[r] : base;
+      q = in ? R.inc[r] : q;
+      st = in ? R.start[r] : st;
+    }
+  });
+  return base + (unsigned)(j - st) * q;
+}
 constexpr int LW_WAVES = 16;     // wavefronts per channel
 constexpr int LW_MAXB = N0_MAXB; // blocks per launch (LDS notes per block)
 template <int K>
@@ -998,7 +1079,8 @@ __global__ __launch_bounds__(64 * LW_WAVES) void kh_demod_linear_w(float2 *__res
                                                                    kh_status *__restrict__ status, int status_stride,
                                                                    const int *__restrict__ list) {
   __shared__ float sh_max[LW_MAXB], sh_energy[LW_MAXB], sh_gain[LW_MAXB];
-  __shared__ unsigned char sh_done[LW_MAXB]; // 1: phase 2 has written the block itself
+  __shared__ int sh_hang[LW_MAXB];
+  __shared__ unsigned char sh_done[LW_MAXB]; // 1: phase 2 has written the block itself; 2: a recovery without attack
   __shared__ __attribute__((aligned(16))) float gtab[64 * K + 8];                                   // recovery products of one block (wavefront 0)
   int const lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   int const ch = list[blockIdx.x];
@@ -1012,6 +1094,10 @@ __global__ __launch_bounds__(64 * LW_WAVES) void kh_demod_linear_w(float2 *__res
   double const phase0 = shift_active ? atan2(s.shift_im, s.shift_re) * (0.5 / M_PI) : 0.0;
   int const H = (int)d.hangtime;
   float const rate = d.recovery_rate, headroom = d.headroom;
+  bool const runs_apply = rate > 0.f && rate < INFINITY;
+  auto rec_prepare = [&](RecRuns &R, float g, int M) -> bool { // the runs of G_0 .. G_M from g
+    return runs_apply && M > 0 && rec_build(R, g, rate, M, lane);
+  };
 
   // sample n = lane + 64 j of block b after the shift
   auto load_block = [&](int b, float2 (&sm)[K], float (&amp)[K], float &energy) {
@@ -1115,6 +1201,28 @@ __global__ __launch_bounds__(64 * LW_WAVES) void kh_demod_linear_w(float2 *__res
         }
         continue;
       }
+      RecRuns R;
+      bool closed = false; // R holds the checked runs from (gain, sample `hang`) to the block's end
+      if (d.agc && gain >= 0.f && hang < olen) {
+        // a block that recovers without an attack: the products are monotonic, so if the block's largest amplitude
+        // does not trip the test against the larger of the first and the last, no sample does.  Phase 2 then only owes the last
+        // product; phase 3 lays the block's products out again, a wavefront per block.
+        int const M0 = olen - hang;
+        closed = rec_prepare(R, gain, M0);
+        if (closed) {
+          float const gend = __uint_as_float(__builtin_amdgcn_readfirstlane(rec_at(R, M0)));
+          if (!(sh_max[b] * fmaxf(gain, gend) > headroom)) {
+            if (lane == 0) {
+              sh_gain[b] = gain;
+              sh_hang[b] = hang;
+              sh_done[b] = 2;
+            }
+            gain = gend;
+            hang = 0;
+            continue;
+          }
+        }
+      }
       // the block in detail: linear.c:127-136 by EVENTS instead of by samples.  From the state (gain, hang) at some sample
       // every later lane can work out, on the assumption that nothing attacks before it, the gain it would be tested
       // against (the iterated fp32 products G_0 = gain, G_{k+1} = fl(G_k * rate), exactly the reference's sequence of
@@ -1160,7 +1268,8 @@ __global__ __launch_bounds__(64 * LW_WAVES) void kh_demod_linear_w(float2 *__res
         // (k < 0: still hanging); the recovery products are laid out once, by one lane, one dependent multiply each
         int M = olen - pos - hang;
         M = M < 0 ? 0 : M;
-        if (M > 0) {
+        if (M > 0 && !(pos == 0 && closed)) closed = rec_prepare(R, gain, M); // (pass 1 may inherit the runs)
+        if (M > 0 && !closed) {
           if (lane == 0) { // (16-byte LDS writes: a write per product doubled the cost of a step of the chain)
             float g = gain;
             for (int m = 0; m <= M; m += 8) { // the table has room for the overshoot (64 K + 8 entries)
@@ -1190,8 +1299,8 @@ __global__ __launch_bounds__(64 * LW_WAVES) void kh_demod_linear_w(float2 *__res
           int const k = n - pos - hang;
           bool const rec = M > 0 && k >= 0 && n < olen;
           int const kk = rec ? k : 0;
-          float const P = rec ? gtab[kk] : tg;
-          Q[jj] = rec ? gtab[kk + 1] : tg;
+          float const P = !rec ? tg : closed ? __uint_as_float(rec_at(R, kk)) : gtab[kk];
+          Q[jj] = !rec ? tg : closed ? __uint_as_float(rec_at(R, kk + 1)) : gtab[kk + 1];
           float const t = isnan(P) ? INFINITY : amp[jj] * P; // linear.c:127: isnan(gain) || amplitude * gain > headroom
           unsigned long long const f = __builtin_amdgcn_ballot_w64(n >= pos && n < olen && t > headroom);
           if (f != 0 && first == olen) first = 64 * jj + __builtin_ctzll(f);
@@ -1205,7 +1314,7 @@ __global__ __launch_bounds__(64 * LW_WAVES) void kh_demod_linear_w(float2 *__res
           if ((first >> 6) == jj) gnew = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(gatt[jj]), first & 63));
         });
         if (first == olen) {
-          if (M > 0) gain = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(gtab[M])));
+          if (M > 0) gain = __int_as_float(__builtin_amdgcn_readfirstlane(closed ? (int)rec_at(R, M) : __float_as_int(gtab[M])));
           int const left = hang - (olen - pos);
           hang = left > 0 ? left : 0;
           pos = olen;
@@ -1247,6 +1356,22 @@ __global__ __launch_bounds__(64 * LW_WAVES) void kh_demod_linear_w(float2 *__res
 #pragma unroll
     for (int j = 0; j < K; j++) gn[j] = g;
     store_block(b, sm, amp, gn, sh_energy[b], g);
+  }
+  for (int b = wave; b < nblocks; b += LW_WAVES) {
+    if (sh_done[b] != 2) continue; // uniform
+    float const g0 = sh_gain[b];
+    int const h0 = sh_hang[b], M = olen - h0; // sample n >= h0 leaves the gain G_{n - h0 + 1}
+    RecRuns R;
+    rec_build(R, g0, rate, M, lane); // (the runs phase 2 found)
+    float2 sm[K];
+    float amp[K], gn[K], energy;
+    load_block(b, sm, amp, energy);
+#pragma unroll
+    for (int j = 0; j < K; j++) {
+      int const k = lane + 64 * j - h0;
+      gn[j] = (k >= 0 && k < M) ? __uint_as_float(rec_at(R, k + 1)) : g0;
+    }
+    store_block(b, sm, amp, gn, sh_energy[b], __uint_as_float(rec_at(R, M)));
   }
 }
 
