@@ -1254,7 +1254,70 @@ __global__ __launch_bounds__(64 * LW_WAVES) void kh_demod_linear_w(float2 *__res
         }
       };
       int pos = 0, events = 0; // position in the block; passes spent on it
+      // While the hang counter outlasts the block (modes.txt: 1.1 s) the gain only moves at attacks, and a sample
+      // attacks when it is larger than the one the gain stands for: the attacks are the running maxima, a prefix scan
+      // (in noise ln(olen) of them follow the first: event by event they were the block's whole cost).  The scan is
+      // only the proposal -- fl(a * fl(headroom / a')) > headroom is not quite a > a' -- so the proposed gains are then
+      // held, all samples at once, against linear.c:127-136 itself: the gain before sample n + 1 must be what sample n
+      // leaves of the gain before it.  By induction from `gain` that makes every one of them the reference's; if one
+      // fails (a near tie) nothing has been touched and the passes below take over.
+      float cur_amp = headroom / gain; // the amplitude the gain stands for (exact after an attack in this block)
+      bool scan_failed = false;
+      auto record_scan = [&]() -> bool {
+        float cc = cur_amp, cg = gain; // largest amplitude so far and the gain it set
+        float prev_after = gain;
+        int last_att = -1;
+        bool bad = false;
+        static_for<K>([&](auto jc) {
+          constexpr int jj = decltype(jc)::value;
+          int const n = lane + 64 * jj;
+          bool const active = n >= pos && n < olen;
+          int sc = __float_as_int(active ? amp[jj] : -1.f), sg = __float_as_int(gatt[jj]);
+          int const ident = __float_as_int(-1.f);
+          // inclusive scan over the lanes of (larger amplitude, its gain), the earlier one on a tie
+#define KH_REC_STEP(CTRL, ROWS)                                                           \
+          {                                                                               \
+            int const pc = __builtin_amdgcn_update_dpp(ident, sc, CTRL, ROWS, 0xf, false); \
+            int const pg = __builtin_amdgcn_update_dpp(0, sg, CTRL, ROWS, 0xf, false);     \
+            bool const mine = __int_as_float(sc) > __int_as_float(pc);                     \
+            sc = mine ? sc : pc;                                                           \
+            sg = mine ? sg : pg;                                                           \
+          }
+          // (where a move brings nothing, pc is the identity -1 and only a NaN amplitude "loses": it takes the identity's
+          // gain 0 along, and never wins later; the check below sees through it: a NaN never attacks)
+          KH_REC_STEP(0x111, 0xf) // row_shr:1
+          KH_REC_STEP(0x112, 0xf) // row_shr:2
+          KH_REC_STEP(0x114, 0xf) // row_shr:4
+          KH_REC_STEP(0x118, 0xf) // row_shr:8
+          KH_REC_STEP(0x142, 0xa) // row_bcast:15 into rows 1, 3
+          KH_REC_STEP(0x143, 0xc) // row_bcast:31 into rows 2, 3
+#undef KH_REC_STEP
+          int const ec = __builtin_amdgcn_update_dpp(ident, sc, 0x138, 0xf, 0xf, false); // wave_shr:1: exclusive
+          int const eg = __builtin_amdgcn_update_dpp(0, sg, 0x138, 0xf, 0xf, false);
+          float const gb = __int_as_float(ec) > cc ? __int_as_float(eg) : cg; // the gain sample n is tested against
+          float const tc = __int_as_float(__builtin_amdgcn_readlane(sc, 63)), tg = __int_as_float(__builtin_amdgcn_readlane(sg, 63));
+          if (tc > cc) cc = tc, cg = tg; // uniform
+          bool const attack = active && amp[jj] * gb > headroom;
+          float const gaft = attack ? gatt[jj] : gb;
+          int const nb = __builtin_amdgcn_update_dpp(0, __float_as_int(gb), 0x130, 0xf, 0xf, false); // wave_shl:1: lane + 1's
+          bad = bad || (lane < 63 && nb != __float_as_int(gaft)) ||
+                (lane == 0 && __float_as_int(gb) != __float_as_int(prev_after));
+          prev_after = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(gaft), 63));
+          unsigned long long const f = __builtin_amdgcn_ballot_w64(attack);
+          if (f) last_att = 64 * jj + 63 - __builtin_clzll(f);
+          if (active) gn[jj] = gaft; // (samples from pos on are rewritten by whatever finishes the block)
+        });
+        if (__builtin_amdgcn_ballot_w64(bad)) return false;
+        gain = prev_after;
+        hang = last_att >= 0 ? H - (olen - 1 - last_att) : hang - (olen - pos);
+        pos = olen;
+        return true;
+      };
       while (pos < olen) {     // uniform
+        if (H >= olen && hang >= olen - pos && gain >= 0.f && !scan_failed) {
+          if (record_scan()) break;
+          scan_failed = true;
+        }
         if (++events > AGC_MAX_EVENTS) { // attacks come thick: the rest of the block sample by sample
           static_for<K>([&](auto jc) {
             constexpr int jj = decltype(jc)::value;
@@ -1319,6 +1382,10 @@ __global__ __launch_bounds__(64 * LW_WAVES) void kh_demod_linear_w(float2 *__res
           hang = left > 0 ? left : 0;
           pos = olen;
         } else {
+          static_for<K>([&](auto jc) {
+            constexpr int jj = decltype(jc)::value;
+            if ((first >> 6) == jj) cur_amp = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(amp[jj]), first & 63));
+          });
           gain = gnew;
           hang = H;
           pos = first + 1;
