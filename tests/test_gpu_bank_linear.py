@@ -190,3 +190,70 @@ def test_agc_regimes(hip):
                 assert abs(st["agc_gain"] - sig["agc_gain"]) <= 1e-4 * abs(sig["agc_gain"]), (c, call, b, st["agc_gain"], sig["agc_gain"])
     assert ties <= 6
     bank.close()
+
+
+@pytest.mark.gpu
+def test_agc_runs_and_record_scan(hip):
+    """The two shortcuts of kh_demod_linear_w's AGC walk against the oracle's sample loop (linear.c:127-136), on the inputs
+    that strain them.  Recovery products as runs of constant bit-pattern step: through a power of two upwards (7.99 -> 8)
+    and, with a rate below 1, downwards (4.001 -> 4); a rate of exactly 1; a rate so fast that a block has more runs than
+    the kernel keeps (the table route); a gain that starts denormal.  Attacks as running maxima: a carrier of constant
+    amplitude (every sample within an ulp of the one the gain stands for: ties), alone and with a step up in the middle
+    of a block; hang times beyond the block, inside it (the event route) and zero.  Float audio to 2e-4 of the block's
+    peak and the status gain to 1e-4, as in test_agc_regimes; a block outside must be a branch tie by
+    tools/fuzz_linear.is_agc_tie (a carrier of constant amplitude under an AGC without hang sits AT the threshold, and
+    the two basebands differ in the last bits)."""
+    import sys
+    tools = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools")
+    if tools not in sys.path:
+        sys.path.insert(0, tools)
+    from fuzz_linear import is_agc_tie
+    ties = []
+    T, calls = 3, 2
+    n = T * calls * L
+    t = np.arange(n) / FS
+    quiet = synth.noise(n, 1e-7, 11).astype(np.complex64)
+    env = np.ones(n)
+    env[int(2.4 * L):] = 1.7          # a step up inside block 2
+    env[int(4.2 * L):] = 0.4          # and down inside block 4
+    carrier = (synth.noise(n, 1e-9, 12) + 0.01 * env * np.exp(2j * np.pi * 1500 * t)).astype(np.complex64)
+    slow = RECOVERY
+    cases = [dict(input=0, hangtime=0.0, recovery_rate=slow, agc_gain=7.99, channels=1),
+             dict(input=0, hangtime=0.0, recovery_rate=0.99999, agc_gain=4.001, channels=1),
+             dict(input=0, hangtime=0.0, recovery_rate=1.0, agc_gain=3.0, channels=2),
+             dict(input=0, hangtime=0.0, recovery_rate=1.002, agc_gain=1.0, channels=1),
+             dict(input=0, hangtime=500.0, recovery_rate=slow, agc_gain=1e-40, channels=1),
+             dict(input=1, hangtime=1.1 * 48000, recovery_rate=slow, agc_gain=AGC0, channels=1),
+             dict(input=1, hangtime=1.1 * 48000, recovery_rate=slow, agc_gain=AGC0, channels=2),
+             dict(input=1, hangtime=300.0, recovery_rate=slow, agc_gain=AGC0, channels=1),
+             dict(input=1, hangtime=0.0, recovery_rate=1.002, agc_gain=AGC0, channels=1),
+             dict(input=1, hangtime=0.0, recovery_rate=slow, agc_gain=AGC0, channels=1, env=1)]
+    bank = hip.Bank(L, M, D, 2, len(cases), T, FS)
+    pipe = pipeline.Pipeline(L, M, D, FS, n_inputs=2)
+    for c, kw in enumerate(cases):
+        kw = dict(kw, low=100.0, high=3000.0, agc=1, headroom=HEADROOM)
+        bank.set_channel(c, demod=hip.KH_DEMOD_LINEAR, **kw)
+        pipe.add_channel(demod="linear", **kw)
+    for call in range(calls):
+        bank.write_input(0, quiet[call * T * L:(call + 1) * T * L])
+        bank.write_input(1, carrier[call * T * L:(call + 1) * T * L])
+        bank.execute(T)
+        for b in range(T):
+            lo = (call * T + b) * L
+            outs, _ = pipe.run_block([quiet[lo:lo + L], carrier[lo:lo + L]])
+            for c, kw in enumerate(cases):
+                _y, audio, sig = outs[c]
+                nch = 1 if kw.get("env") else kw["channels"]
+                ga = bank.audio(c, T)[b * OLEN * nch:(b + 1) * OLEN * nch]
+                if call == 0 and b == 0:  # (start-up on amplified round-off: see test_linear_and_am_bank)
+                    ga, audio = ga[600 * nch:], audio[600 * nch:]
+                scale = max(float(np.abs(audio).max()), 1e-30)
+                err = float(np.abs(ga - audio).max()) / scale
+                if err > 2e-4:
+                    assert is_agc_tie(ga, audio, kw["recovery_rate"], kw["hangtime"], nch), (c, kw, call, b, err, getattr(is_agc_tie, "why", ""))
+                    ties.append((c, call, b))
+                    continue
+                st = bank.status(c, T)[b]
+                assert abs(st["agc_gain"] - sig["agc_gain"]) <= 1e-4 * abs(sig["agc_gain"]), (c, call, b, st["agc_gain"], sig["agc_gain"])
+    assert all(cases[c]["input"] == 1 and cases[c]["hangtime"] < OLEN for c, _, _ in ties), ties  # only where ties are at home
+    bank.close()
