@@ -1069,7 +1069,7 @@ __device__ __forceinline__ unsigned rec_at(RecRuns const &R, int j) { // bit pat
   });
   return base + (unsigned)(j - st) * q;
 }
-constexpr int LW_WAVES = 16;     // wavefronts per channel
+constexpr int LW_WAVES = 8;      // wavefronts per channel (16 are quicker alone, but cost the next launch's transform kernels more registers)
 constexpr int LW_MAXB = N0_MAXB; // blocks per launch (LDS notes per block)
 template <int K>
 __global__ __launch_bounds__(64 * LW_WAVES) void kh_demod_linear_w(float2 *__restrict__ baseband, size_t bb_stride, int olen,
@@ -1085,7 +1085,14 @@ __global__ __launch_bounds__(64 * LW_WAVES) void kh_demod_linear_w(float2 *__res
   int const lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   int const ch = list[blockIdx.x];
   DemodDesc const d = descs[ch];
-  DemodState s = states[ch];
+  // (the fields this kernel uses, one by one: a copy of the whole record leaves an alloca behind for the rest, and the
+  // compiler parks it in LDS -- 60 KB a workgroup)
+  DemodState *const sp = states + ch;
+  struct {
+    double shift_re, shift_im;
+    int shift_steps, hangcount, pll_lock;
+    float snr, agc_gain;
+  } s = {sp->shift_re, sp->shift_im, sp->shift_steps, sp->hangcount, sp->pll_lock, sp->snr, sp->agc_gain};
   float2 *y = baseband + (size_t)ch * bb_stride;
   float *ao = audio ? audio + (size_t)ch * pcm_stride : nullptr;
   int16_t *po = pcm + (size_t)ch * pcm_stride;
@@ -1148,20 +1155,19 @@ __global__ __launch_bounds__(64 * LW_WAVES) void kh_demod_linear_w(float2 *__res
       }
     }
     level = wave_sum(level);
-    if (lane == 0) {
-      kh_status r;
-      r.bb_power = energy_sum / olen;
-      r.snr = s.snr;
-      r.foffset = 0.f;
-      r.pdeviation = 0.f;
-      r.cphase = 0.f;
-      r.lock_timer = 0.f;
-      r.pll_lock = s.pll_lock;
-      r.output_level = level / (olen * d.channels);
-      r.agc_gain = gain_after;
-      r.squelch_open = 0;
-      r.reserved[0] = r.reserved[1] = 0.f;
-      status[(size_t)ch * status_stride + b] = r;
+    if (lane == 0) { // (field by field: a local record here is an alloca that the compiler moves to LDS, 60 KB a workgroup)
+      kh_status *const r = status + (size_t)ch * status_stride + b;
+      r->bb_power = energy_sum / olen;
+      r->snr = s.snr;
+      r->foffset = 0.f;
+      r->pdeviation = 0.f;
+      r->cphase = 0.f;
+      r->lock_timer = 0.f;
+      r->pll_lock = s.pll_lock;
+      r->output_level = level / (olen * d.channels);
+      r->agc_gain = gain_after;
+      r->squelch_open = 0;
+      r->reserved[0] = r->reserved[1] = 0.f;
     }
   };
 
@@ -1402,13 +1408,12 @@ __global__ __launch_bounds__(64 * LW_WAVES) void kh_demod_linear_w(float2 *__res
         double ph = phase0 + d.shift_freq * (double)total;
         ph -= rint(ph);
         sincospi(2.0 * ph, &sn, &cs);
-        s.shift_re = cs;
-        s.shift_im = sn;
+        sp->shift_re = cs;
+        sp->shift_im = sn;
       }
-      s.shift_steps = (int)((s.shift_steps + total) % 16384); // Renorm_rate, osc.c:11
-      s.agc_gain = gain;
-      s.hangcount = hang;
-      states[ch] = s;
+      sp->shift_steps = (int)((s.shift_steps + total) % 16384); // Renorm_rate, osc.c:11
+      sp->agc_gain = gain;
+      sp->hangcount = hang;
     }
   }
   __syncthreads();
@@ -1577,6 +1582,10 @@ int launch_demod(hipStream_t st, float2 *baseband, size_t bb_stride, int olen, i
   (void)nchan;
   if (nblocks <= 0) return 0;
   kh_status *stt = static_cast<kh_status *>(status);
+  // the first n_lin_nopll entries of lin_list have opt.pll off: one workgroup each (kh_demod_linear_w); the others keep
+  // the lane-per-channel loop.  KA9Q_HIP_LINEAR_WAVE=0 sends every linear channel there (A/B switch).
+  static int const lin_wave_env = getenv("KA9Q_HIP_LINEAR_WAVE") ? atoi(getenv("KA9Q_HIP_LINEAR_WAVE")) : 1;
+  int const nw = (lin_wave_env && olen <= 1024 && nblocks <= LW_MAXB) ? (n_lin_nopll < n_lin ? n_lin_nopll : n_lin) : 0;
   if (n_fm > 0) {
     if (olen < 2 || olen > 8192 - 1) {
       set_error("FM demodulator: olen %d outside [2, 8192]", olen);
@@ -1601,10 +1610,6 @@ int launch_demod(hipStream_t st, float2 *baseband, size_t bb_stride, int olen, i
     else
       hipLaunchKernelGGL(kh_fm_finish_w<16>, grid, dim3(256), 0, st, F, npairs, nfin, Z);
   }
-  // the first n_lin_nopll entries of lin_list have opt.pll off: one workgroup each (kh_demod_linear_w); the others keep
-  // the lane-per-channel loop.  KA9Q_HIP_LINEAR_WAVE=0 sends every linear channel there (A/B switch).
-  static int const lin_wave_env = getenv("KA9Q_HIP_LINEAR_WAVE") ? atoi(getenv("KA9Q_HIP_LINEAR_WAVE")) : 1;
-  int const nw = (lin_wave_env && olen <= 1024 && nblocks <= LW_MAXB) ? (n_lin_nopll < n_lin ? n_lin_nopll : n_lin) : 0;
   if (nw > 0) {
     auto const kern = olen <= 256 ? kh_demod_linear_w<4> : olen <= 512 ? kh_demod_linear_w<8> : kh_demod_linear_w<16>;
     hipLaunchKernelGGL(kern, dim3(nw), dim3(64 * LW_WAVES), 0, st, baseband, bb_stride, olen, nblocks, desc, state, audio, pcm, pcm_stride,
