@@ -340,6 +340,8 @@ def main():
         sys.exit(2)
     # Rehearsal on a one-GPU box (not a measurement): KA9Q_BENCH_REHEARSE=1 puts every rank on device 0 and runs the
     # collectives over gloo on host tensors, so that the N > 1 control flow can be exercised without N GPUs.
+    # Two ranks at most: with four processes on one GPU their streams outnumber the hardware queues and a 70 us step
+    # takes milliseconds (seen: the 0.25 s prewarm of one rank did not end within minutes).
     rehearse = os.environ.get("KA9Q_BENCH_REHEARSE", "0") == "1"
     if rehearse:
         local_rank = 0
@@ -354,8 +356,15 @@ def main():
         else:
             dist.init_process_group("nccl", device_id=device)
 
+    verbose = os.environ.get("KA9Q_BENCH_VERBOSE", "0") == "1"
+
+    def note(msg):  # progress on stderr (KA9Q_BENCH_VERBOSE=1): where a multi-rank run is, should one ever stall
+        if verbose:
+            print(f"[bench rank {rank}] {time.strftime('%H:%M:%S')} {msg}", file=sys.stderr, flush=True)
+
     import pyka9q
     assert pyka9q.lib().ka9q_hip_init(local_rank) == 0, pyka9q.last_error()
+    note("library up")
 
     # 64 channels per GPU on the 12.5 kHz raster: the job's 64*world channels, sharded contiguously in frequency
     full_plan = workloads.config2_plan(C * world)
@@ -392,9 +401,11 @@ def main():
         for _ in range(50):
             step()
         bank.sync()
+    note("prewarm done")
     for _ in range(args.warmup):
         step()
     barrier()
+    note("warm-up done, timed region starts")
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
@@ -405,6 +416,7 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
 
+    note(f"timed region done: {dt:.4f} s")
     # per-kernel durations: the same K steps with a HIP event pair around every stage on the bank's stream
     bank.profile(1)
     for _ in range(args.steps):
@@ -417,6 +429,7 @@ def main():
     # timed region does) against an RCCL broadcast over xGMI of the step's raw input (option B: saves host fan-out, not
     # the FFT) or of its spectrum (option C: saves the FFT on the peers).  Timed here, outside the timed region.
     probe = None
+    note("stage times taken")
     if dist is not None:
         try:
             def bcast_ms(t):
@@ -441,12 +454,13 @@ def main():
         except Exception as e:  # the probe must never cost the bench line
             probe = {"error": repr(e)}
 
+    note(f"exchange probe: {probe}")
     # sanity: the run demodulated something (squelch open on the strongest channel)
     stat = bank.status(C - 1, T)
     pcm = bank.pcm(C - 1, T)
     assert args.demod != "fm" or (stat["squelch_open"].max() > 0 and np.abs(pcm).max() > 100), "bench produced no audio"
     x_cpu = None
-    if rank == 0 and not args.no_cpu:
+    if rank == 0 and world == 1 and not args.no_cpu:  # (the CPU baseline belongs to the N = 1 line)
         x_cpu = x[:6 * L].cpu().numpy().view(np.complex64).reshape(-1)
     bank.close()
     del x
