@@ -720,15 +720,15 @@ __device__ __forceinline__ void fm_finish_wave(FinishArgs const &F, int q, int l
   }
 }
 
-// workgroups [0, nfin) carry four finish wavefronts each; workgroups nfin + i (if any) are kh_n0_final's work for input i
+// workgroups [0, nfin) carry blockDim.x / 64 finish wavefronts each (eight: fewer, larger workgroups dispatch faster); workgroups nfin + i (if any) are kh_n0_final's work for input i
 template <int K>
-__global__ __launch_bounds__(256) void kh_fm_finish_w(FinishArgs F, int npairs, int nfin, N0FinalArgs Z) {
+__global__ __launch_bounds__(1024) void kh_fm_finish_w(FinishArgs F, int npairs, int nfin, N0FinalArgs Z) {
   __shared__ float sv[N0_MAXB], se[N0_MAXB];
   if ((int)blockIdx.x >= nfin) {
     n0_final_body(Z, blockIdx.x - nfin, sv, se);
     return;
   }
-  int const q = blockIdx.x * 4 + (threadIdx.x >> 6);
+  int const q = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
   if (q < npairs) fm_finish_wave<K>(F, q, threadIdx.x & 63);
 }
 
@@ -1594,7 +1594,12 @@ int launch_demod(hipStream_t st, float2 *baseband, size_t bb_stride, int olen, i
     FinishArgs const F{olen, nblocks, desc, state, fm.parity, fm.stat, status_stride, fm.work, bb_stride, fm.carry,
                        fm.decay_pow, audio, pcm, pcm_stride, pcm_big_endian, stt, status_stride, fm_list, n_fm};
     int const npairs = n_fm * nblocks;
-    int const nfin = (npairs + 3) / 4;
+    // wavefronts per workgroup: fewer, larger workgroups dispatch faster (configs[1], us per step: 1: 98, 2: 77, 4: 68.6,
+    // 8: 66.8, 16: 66), but in a bank that also has wave-resident linear channels eight cost the step 15 us (config 3's
+    // share 168 -> 182-190: the larger workgroups stand in the way of the next launch's transform kernels for longer)
+    static int const wpb_env = getenv("KA9Q_HIP_FINISH_WPB") ? std::min(std::max(atoi(getenv("KA9Q_HIP_FINISH_WPB")), 1), 16) : 0;
+    int const wpb = wpb_env ? wpb_env : nw > 0 ? 4 : 8;
+    int const nfin = (npairs + wpb - 1) / wpb;
     int const K = (olen + 63) / 64;
     bool const wave = fm_finish_wave_usable(olen, nblocks);
     N0FinalArgs const Z = (wave && n0final) ? *n0final : N0FinalArgs{};
@@ -1604,11 +1609,11 @@ int launch_demod(hipStream_t st, float2 *baseband, size_t bb_stride, int olen, i
                          state, fm.parity, fm.stat, status_stride, fm.work, bb_stride, fm.carry, fm.decay_pow, audio, pcm,
                          pcm_stride, pcm_big_endian, stt, status_stride, fm_list);
     else if (K <= 4)
-      hipLaunchKernelGGL(kh_fm_finish_w<4>, grid, dim3(256), 0, st, F, npairs, nfin, Z);
+      hipLaunchKernelGGL(kh_fm_finish_w<4>, grid, dim3(64 * wpb), 0, st, F, npairs, nfin, Z);
     else if (K <= 8)
-      hipLaunchKernelGGL(kh_fm_finish_w<8>, grid, dim3(256), 0, st, F, npairs, nfin, Z);
+      hipLaunchKernelGGL(kh_fm_finish_w<8>, grid, dim3(64 * wpb), 0, st, F, npairs, nfin, Z);
     else
-      hipLaunchKernelGGL(kh_fm_finish_w<16>, grid, dim3(256), 0, st, F, npairs, nfin, Z);
+      hipLaunchKernelGGL(kh_fm_finish_w<16>, grid, dim3(64 * wpb), 0, st, F, npairs, nfin, Z);
   }
   if (nw > 0) {
     auto const kern = olen <= 256 ? kh_demod_linear_w<4> : olen <= 512 ? kh_demod_linear_w<8> : kh_demod_linear_w<16>;
