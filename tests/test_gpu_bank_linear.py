@@ -193,7 +193,8 @@ def test_agc_regimes(hip):
 
 
 @pytest.mark.gpu
-def test_agc_runs_and_record_scan(hip):
+@pytest.mark.parametrize("dec", [4, 8, 16])  # olen 960, 480, 240: the kernel's three register tilings
+def test_agc_runs_and_record_scan(hip, dec):
     """The two shortcuts of kh_demod_linear_w's AGC walk against the oracle's sample loop (linear.c:127-136), on the inputs
     that strain them.  Recovery products as runs of constant bit-pattern step: through a power of two upwards (7.99 -> 8)
     and, with a rate below 1, downwards (4.001 -> 4); a rate of exactly 1; a rate so fast that a block has more runs than
@@ -210,6 +211,7 @@ def test_agc_runs_and_record_scan(hip):
     from fuzz_linear import is_agc_tie
     ties = []
     T, calls = 3, 2
+    olen = L // dec
     n = T * calls * L
     t = np.arange(n) / FS
     quiet = synth.noise(n, 1e-7, 11).astype(np.complex64)
@@ -228,8 +230,8 @@ def test_agc_runs_and_record_scan(hip):
              dict(input=1, hangtime=300.0, recovery_rate=slow, agc_gain=AGC0, channels=1),
              dict(input=1, hangtime=0.0, recovery_rate=1.002, agc_gain=AGC0, channels=1),
              dict(input=1, hangtime=0.0, recovery_rate=slow, agc_gain=AGC0, channels=1, env=1)]
-    bank = hip.Bank(L, M, D, 2, len(cases), T, FS)
-    pipe = pipeline.Pipeline(L, M, D, FS, n_inputs=2)
+    bank = hip.Bank(L, M, dec, 2, len(cases), T, FS)
+    pipe = pipeline.Pipeline(L, M, dec, FS, n_inputs=2)
     for c, kw in enumerate(cases):
         kw = dict(kw, low=100.0, high=3000.0, agc=1, headroom=HEADROOM)
         bank.set_channel(c, demod=hip.KH_DEMOD_LINEAR, **kw)
@@ -244,9 +246,9 @@ def test_agc_runs_and_record_scan(hip):
             for c, kw in enumerate(cases):
                 _y, audio, sig = outs[c]
                 nch = 1 if kw.get("env") else kw["channels"]
-                ga = bank.audio(c, T)[b * OLEN * nch:(b + 1) * OLEN * nch]
+                ga = bank.audio(c, T)[b * olen * nch:(b + 1) * olen * nch]
                 if call == 0 and b == 0:  # (start-up on amplified round-off: see test_linear_and_am_bank)
-                    ga, audio = ga[600 * nch:], audio[600 * nch:]
+                    ga, audio = ga[(600 * 4 // dec) * nch:], audio[(600 * 4 // dec) * nch:]
                 scale = max(float(np.abs(audio).max()), 1e-30)
                 err = float(np.abs(ga - audio).max()) / scale
                 if err > 2e-4:
@@ -255,5 +257,5 @@ def test_agc_runs_and_record_scan(hip):
                     continue
                 st = bank.status(c, T)[b]
                 assert abs(st["agc_gain"] - sig["agc_gain"]) <= 1e-4 * abs(sig["agc_gain"]), (c, call, b, st["agc_gain"], sig["agc_gain"])
-    assert all(cases[c]["input"] == 1 and cases[c]["hangtime"] < OLEN for c, _, _ in ties), ties  # only where ties are at home
+    assert all(cases[c]["input"] == 1 and cases[c]["hangtime"] < 960 for c, _, _ in ties), ties  # only where ties are at home
     bank.close()

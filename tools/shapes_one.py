@@ -15,6 +15,7 @@ jobs = [
     (workloads.CONFIG5, workloads.config5_plan(), 32, "config 5"),
 ]
 shape, plan, nb, label = jobs[which]
+nb = int(os.environ.get("KA9Q_SHAPE_T", nb))  # experiment: blocks per launch
 if len(sys.argv) > 3 and sys.argv[3] == "noagc":  # experiment: the linear channels without AGC (no serial walk)
     plan = [dict(ch, agc=0) if ch["demod"] == "linear" else ch for ch in plan]
 print(json.dumps(bench.measure_shape(pyka9q, torch, torch.device("cuda:0"), shape, plan, nb, label, steps=steps)))
