@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Randomised parity sweep of the bank's linear.c / am.c demodulators against the oracle pipeline (test
-infrastructure, run on a GPU box): tools/fuzz_linear.py [cases] [seed].  Each case is a bank of 6 channels with random
+infrastructure, run on a GPU box): tools/fuzz_linear.py [cases] [seed] [decimation 4|8|16].  Each case is a bank of 6 channels with random
 mode parameters (filter edges, AGC on/off, hang time, recovery rate, start gain, headroom, mono/stereo, ISB fold,
 envelope detection, frequency shift, am.c) over the four test signals of tests/test_gpu_bank_linear.py, random block and
 launch counts; the bars are that test's (audio 2e-4 of the block's peak, PCM +-1 LSB, status 1e-4).  The PLL modes
@@ -17,7 +17,10 @@ for p in (ROOT, os.path.join(ROOT, "oracle"), os.path.join(ROOT, "ka9q-radio_amd
 import orc  # noqa: E402
 import pipeline  # noqa: E402
 import pyka9q as hip  # noqa: E402
-from test_gpu_bank_linear import FS, L, M, D, OLEN, _signal  # noqa: E402
+from test_gpu_bank_linear import FS, L, M, _signal  # noqa: E402
+
+D = 4  # decimation (main() takes 4, 8 or 16 from the command line: olen 960, 480, 240, kh_demod_linear_w's three tilings)
+OLEN = L // D
 
 SIGS = ["usb", "am", "dsb", "iq"]
 
@@ -78,7 +81,7 @@ def run_case(rng, k, ties):
                     sl = slice(b * OLEN * nch, (b + 1) * OLEN * nch)
                     ga, gp = g_aud[c][sl], g_pcm[c][sl]
                     if call == 0 and b == 0:  # start-up on amplified round-off (see the fixed test)
-                        ga, gp, audio = ga[600 * nch:], gp[600 * nch:], audio[600 * nch:]
+                        ga, gp, audio = ga[(2400 // D) * nch:], gp[(2400 // D) * nch:], audio[(2400 // D) * nch:]
                     scale = max(float(np.abs(audio).max()), 1e-6)
                     err = float(np.abs(ga - audio).max()) / scale
                     worst = max(worst, err)
@@ -164,6 +167,9 @@ def _is_agc_tie(ga, audio, recovery_rate, hangtime, nch=1):
 def main():
     cases = int(sys.argv[1]) if len(sys.argv) > 1 else 30
     seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+    global D, OLEN
+    D = int(sys.argv[3]) if len(sys.argv) > 3 else 4
+    OLEN = L // D
     rng = np.random.default_rng(seed)
     assert hip.lib().ka9q_hip_init(0) == 0, hip.last_error()
     bad = 0
