@@ -17,7 +17,7 @@ for p in (ROOT, os.path.join(ROOT, "oracle"), os.path.join(ROOT, "ka9q-radio_amd
 import orc  # noqa: E402
 import pipeline  # noqa: E402
 import pyka9q as hip  # noqa: E402
-from fuzz_linear import SIGS, draw_channel, is_agc_tie  # noqa: E402
+from fuzz_linear import SIGS, draw_channel, is_agc_tie, tie_goes_on, pcm_follows_audio  # noqa: E402
 from test_gpu_bank_linear import FS, L, M, D, OLEN, _signal  # noqa: E402
 
 
@@ -42,6 +42,7 @@ def run_case(rng, ties):
         bank.set_channel(c, demod=ids[dem], **kw)
         pipe.add_channel(demod=dem, **kw)
     hist = []  # the oracle's status records, block by block (for the diagnostics below)
+    open_tie = {}  # channels inside a divergence that began with a verified AGC branch tie (tools/fuzz_linear.py)
     try:
         for call in range(calls):
             for i, s in enumerate(SIGS):
@@ -100,21 +101,37 @@ def run_case(rng, ties):
                         i = int(np.argmax(rel > 5e-5))
                         # the hang AGC's branch tie (tools/fuzz_linear.py), with a hang time: the side that took the attack
                         # branch holds its gain for hangtime samples while the other recovers
-                        tie = bool(kw.get("agc")) and is_agc_tie(ga, audio, kw["recovery_rate"], kw.get("hangtime", 0.0), nch)
+                        tie = bool(kw.get("agc")) and (is_agc_tie(ga, audio, kw["recovery_rate"], kw.get("hangtime", 0.0), nch) or
+                                                        bool(open_tie.get(c) and tie_goes_on(ga, audio, kw["recovery_rate"], kw.get("hangtime", 0.0), nch)))
                         msg = (f"{what}: audio err {err:.2e}, first beyond 5e-5 at sample {i} of {ga.size}: gpu "
                                f"{np.array2string(ga[max(i - 3, 0):i + 4], precision=7)} oracle "
                                f"{np.array2string(audio[max(i - 3, 0):i + 4], precision=7)}; rel err there "
                                f"{np.array2string(rel[max(i - 3, 0):i + 4], precision=2)}, at the end {rel[-1]:.2e}")
                         if tie:
                             ties.append(msg)
+                            open_tie[c] = True
                             continue
-                        raise AssertionError(msg)
+                        raise AssertionError(msg + "; tie test: " + str(getattr(is_agc_tie, "why", "")))
+                    open_tie[c] = False
                     if d.max() > 1 and kw.get("agc") and is_agc_tie(ga, audio, kw["recovery_rate"], kw.get("hangtime", 0.0), nch):
                         ties.append(what)  # AGC branch tie (tools/fuzz_linear.py)
                         continue
-                    assert d.max() <= 1, f"{what}: pcm max diff {d.max()}, block audio err {err:.2e}"
+                    over = np.flatnonzero(d > 1)
+                    if over.size and pcm_follows_audio(ga, gp, audio, over):
+                        ties.append(f"{what}: PCM exact for the GPU's own audio, block over full scale (tools/fuzz_linear.py)")
+                        continue
+                    if d.max() == 2 and all(abs(abs(float(audio[j])) - 1.0) <= 2e-7 and abs(abs(float(ga[j])) - 1.0) <= 2e-7 for j in over):
+                        ties.append(f"{what}: clip boundary of scaleclip (audio.c:22-28: -32766 -> -32768 at x = -1)")
+                        continue
+                    assert d.max() <= 1, (f"{what}: pcm max diff {d.max()}, block audio err {err:.2e}; audio there gpu "
+                                          f"{[float(ga[j]) for j in over[:4]]} oracle {[float(audio[j]) for j in over[:4]]}")
                     keys = ["bb_power", "agc_gain"] if kw["demod"] == "am" else ["bb_power", "agc_gain", "output_level"]
                     for key in keys:
+                        if key == "output_level" and call == 0 and b == 0:  # (start-up samples count in it: against the GPU's own audio, tools/fuzz_linear.py)
+                            full = np.asarray(g_aud[c][sl], np.float64)
+                            own = float((full * full).sum() / (OLEN * nch))
+                            assert abs(st[key] - own) <= 1e-5 * abs(own) + 1e-12, f"{what}: {key} {st[key]} vs own audio {own}"
+                            continue
                         assert abs(st[key] - sig[key]) <= 1e-4 * abs(sig[key]) + 1e-12, f"{what}: {key} {st[key]} vs {sig[key]}"
     finally:
         bank.close()
@@ -134,10 +151,10 @@ def main():
             print(f"[{k}] ok  {run_case(rng, ties)}", flush=True)
         except AssertionError as e:
             bad += 1
-            print(f"[{k}] BAD {str(e)[:600]}", flush=True)
+            print(f"[{k}] BAD {str(e)[:2400]}", flush=True)
     for t in ties:
         print("agc tie:", t)
-    print(f"{cases} cases, {bad} bad, {len(ties)} blocks with a verified branch tie (AGC attack, or signed zero at a squelch opening), {time.time() - t0:.0f} s")
+    print(f"{cases} cases, {bad} bad, {len(ties)} blocks with a verified branch tie (AGC attack, signed zero at a squelch opening, or scaleclip's clip boundary), {time.time() - t0:.0f} s")
     return 1 if bad else 0
 
 
