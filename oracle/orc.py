@@ -495,8 +495,10 @@ class AfskSession:
         self.L.orc_afsk_init(C.addressof(self.st))
         self.consumed = 0
 
-    def block(self, pcm_be, maxframes=16, maxbits=64):
-        """pcm_be: AFSK_L network-order int16 words.  Returns (baseband[AFSK_L], frames, bits)."""
+    def block(self, pcm_be, maxframes=16, maxbits=64, y_override=None):
+        """pcm_be: AFSK_L network-order int16 words.  Returns (baseband[AFSK_L], frames, bits).
+        y_override: run decode_task's loop over this baseband instead of the session's own filter output (the filter
+        still runs and keeps its history): the sweeps' replay of the reference loop over the GPU's baseband."""
         pcm_be = np.ascontiguousarray(pcm_be, np.int16)
         assert pcm_be.size == AFSK_L
         p = self.L.orc_filter_in_input_r(self.fin)
@@ -506,6 +508,9 @@ class AfskSession:
         self.L.orc_execute_filter_output(self.fout, 0)
         q = self.L.orc_filter_out_output(self.fout)
         y = np.frombuffer((C.c_char * (AFSK_L * 8)).from_address(q), np.complex64, AFSK_L).copy()
+        if y_override is not None:
+            y = np.ascontiguousarray(y_override, np.complex64)
+            assert y.size == AFSK_L
         frames = (Ax25Frame * maxframes)()
         bits = (AfskBit * maxbits)()
         nb = C.c_int(0)

@@ -68,7 +68,13 @@ def _run_pair(hip, L, M, D, fs, chans, x, nblocks_per_call, calls, flat=0, n0=Fa
                 # (a channel whose baseband deviation the referee has accepted is a noise-only channel with the squelch
                 # closed: its PCM is zeros on both sides and is still compared)
                 assert d.max() <= 1, f"pcm ch {c} block {b} call {call}: max diff {d.max()}"
-                assert np.allclose(g_aud[c][sl], audio, rtol=1e-4, atol=2e-5)
+                if not np.allclose(g_aud[c][sl], audio, rtol=1e-4, atol=2e-5):
+                    e = np.abs(g_aud[c][sl] - audio) - 1e-4 * np.abs(audio)
+                    i = int(np.argmax(e))
+                    check(False, "fm_audio", f"FM audio ch {c} block {b} call {call}: worst at sample {i} of {olen}: gpu "
+                          f"{g_aud[c][sl][max(i - 2, 0):i + 3]} oracle {audio[max(i - 2, 0):i + 3]}; {int((e > 2e-5).sum())} samples "
+                          f"beyond the bar; y[0] gpu {g_bb[c][sl][0]!r} oracle {y[0]!r}", call=call, block=b, ch=c, gpu=g_aud[c][sl],
+                          oracle=audio, y_gpu=g_bb[c][sl], y_oracle=y, flat=flat, worst=i, beyond=int((e > 2e-5).sum()))
                 st = g_st[c][b]
                 for key in ("bb_power", "snr", "output_level"):
                     ref = sig[key]
