@@ -64,6 +64,7 @@ def run_case(rng, k, ties):
         bank.set_channel(c, demod=ids[dem], **kw)
         pipe.add_channel(demod=dem, **kw)
     worst = 0.0
+    replay = Replay(chans, int(np.float32(FS) / np.float32(D)))
     open_tie = {}  # channels inside a divergence that began with a verified branch tie
     try:
         for call in range(calls):
@@ -73,6 +74,7 @@ def run_case(rng, k, ties):
             g_pcm = [bank.pcm(c, T) for c in range(len(chans))]
             g_aud = [bank.audio(c, T) for c in range(len(chans))]
             g_st = [bank.status(c, T) for c in range(len(chans))]
+            replay.run(bank, T, OLEN)
             if os.environ.get("KA9Q_FUZZ_DUMP"):  # digests of the GPU's outputs: two builds of the library can be compared bit for bit
                 import zlib
                 with open(os.environ["KA9Q_FUZZ_DUMP"], "a") as f:
@@ -91,6 +93,12 @@ def run_case(rng, k, ties):
                     scale = max(float(np.abs(audio).max()), 1e-6)
                     err = float(np.abs(ga - audio).max()) / scale
                     worst = max(worst, err)
+                    skip = (2400 // D) * nch if call == 0 and b == 0 else 0
+                    st_gain_off = bool(kw.get("agc")) and abs(g_st[c][b]["agc_gain"] - sig["agc_gain"]) > 1e-4 * abs(sig["agc_gain"])
+                    pcm_off = int(np.abs(gp.astype(np.int32) - orc.scaleclip(audio).astype(np.int32)).max()) > 1
+                    if (err > 2e-4 or st_gain_off or pcm_off) and kw.get("agc") and replay.confirms(c, b, g_aud[c][sl], g_pcm[c][sl], g_st[c][b], skip):
+                        ties.append((k, c, float(err), -2, "the reference loop over the GPU's own baseband gives the GPU's output"))
+                        continue
                     if err > 2e-4 and kw.get("agc") and (is_agc_tie(ga, audio, kw["recovery_rate"], kw.get("hangtime", 0.0), nch) or
                                                          (open_tie.get(c) and tie_goes_on(ga, audio, kw["recovery_rate"], kw.get("hangtime", 0.0), nch))):
                         ties.append((k, c, float(err), -1))  # with a hang time the attacking side holds its gain: many steps
@@ -203,6 +211,42 @@ def _is_agc_tie(ga, audio, recovery_rate, hangtime, nch=1):
                       f"ratio range [{ratio.min():.6f}, {ratio.max():.6f}], band {recovery_rate ** (hangtime + 2):.6f}")
     band = recovery_rate ** (hangtime + 2) * (1 + 1e-5)
     return bool(one_step and ratio.max() <= band and ratio.min() >= 1 / band)
+
+
+class Replay:
+    """The reference's demodulator loop (linear.c:57-156 as oracle/ka9q_oracle.c restates it) run over the GPU's OWN
+    baseband, channel by channel and block by block from the first: the last word on a block where the GPU and the
+    oracle part ways at an AGC knife edge.  If this reproduces the GPU's audio to 2e-6 of the block's peak (the bar
+    against the oracle is 2e-4; what is left is the shift oscillator's closed form against its recurrence), its gain
+    to 1e-6 and its PCM to the LSB, the only difference between the GPU and the oracle is their two fp32 basebands.
+    Mono and envelope channels of the linear demodulator only (a stereo channel's baseband is overwritten by its
+    output, linear.c:145)."""
+
+    def __init__(self, chans, out_samprate):
+        self.dem = {}
+        for c, kw in enumerate(chans):
+            if kw["demod"] == "linear" and (kw.get("env") or kw.get("channels", 1) == 1):
+                self.dem[c] = orc.LinearDemod(out_samprate, 0, 0, kw.get("agc", 0), kw.get("env", 0), kw.get("channels", 1),
+                                              kw["headroom"], kw.get("hangtime", 0.0), kw.get("recovery_rate", 1.0), 5.0,
+                                              kw.get("agc_gain", 1.0), kw.get("shift", 0.0))
+        self.out = {}
+
+    def run(self, bank, T, olen):
+        for c, dem in self.dem.items():
+            y = bank.baseband(c, T)
+            for b in range(T):
+                self.out[(c, b)] = dem.block(y[b * olen:(b + 1) * olen].copy())
+
+    def confirms(self, c, b, ga_full, gp_full, st, skip):
+        if (c, b) not in self.out:
+            return False
+        ra, rs = self.out[(c, b)]
+        ga, gp, ra = ga_full[skip:], gp_full[skip:], ra[skip:]
+        peak = max(float(np.abs(ra).max()), 1e-9)
+        d = np.abs(gp.astype(np.int32) - orc.scaleclip(ra).astype(np.int32))
+        return bool(float(np.abs(ga - ra).max()) <= 2e-6 * peak and d.max() <= 1
+                    and abs(float(st["agc_gain"]) - rs["agc_gain"]) <= 1e-6 * abs(rs["agc_gain"])
+                    and (skip > 0 or abs(float(st["output_level"]) - rs["output_level"]) <= 1e-5 * abs(rs["output_level"]) + 1e-12))
 
 
 def pcm_follows_audio(ga, gp, audio, over):
