@@ -90,7 +90,8 @@ def _run_pair(hip, L, M, D, fs, chans, x, nblocks_per_call, calls, flat=0, n0=Fa
                     # compares snr with 4 (fm.c:73)
                     floor = 1e-4 if key == "snr" else 1e-12
                     check(abs(st[key] - ref) <= 1e-4 * abs(ref) + floor, key, f"{key} ch {c} block {b} call {call}: {st[key]} vs {ref}",
-                          call=call, block=b, ch=c, gpu=float(st[key]), oracle=float(ref), y_oracle=y, bb_ok=bb_ok)
+                          call=call, block=b, ch=c, gpu=float(st[key]), oracle=float(ref), y_oracle=y, bb_ok=bb_ok, audio_gpu=g_aud[c][sl],
+                          audio_oracle=audio)
                 res.append((c, b, int(st["squelch_open"]), sig))
                 if st["squelch_open"] or sig["snr"] > 4:
                     for key in ("foffset", "pdeviation"):

@@ -115,6 +115,19 @@ class Referee:
                 self.log.append(f"n0 block {upto}: gpu {g:.6e} float64 {t:.6e} oracle {o:.6e} (gpu-f64 {abs(g - t) / t:.1e}, oracle-f64 {abs(o - t) / t:.1e})")
                 return True
             return False
+        if field == "output_level":
+            # fm.c:135-138: the mean square of the block's audio.  The audio itself has just passed its bar (2e-5 + 1e-4 per
+            # sample); in a block whose audio is all small (a closed squelch's decaying tail, a weak channel) that bar is
+            # wider than 1e-4 of the mean square.  The status is held against the GPU's OWN audio instead, in float64.
+            ag = np.asarray(ctx["audio_gpu"], np.float64)
+            own = float((ag * ag).mean())
+            if abs(g - own) <= 1e-5 * own + 1e-15 and float(np.abs(ag).max()) <= 0.05:
+                self.lvl = getattr(self, "lvl", 0) + 1
+                self.log.append(f"output_level ch {ctx['ch']}: gpu {g:.7g} is the mean square of the GPU's own audio ({own:.7g}) to {abs(g - own) / own:.1e}; "
+                                f"oracle {o:.7g}; audio peak {float(np.abs(ag).max()):.2e}")
+                return True
+            self.log.append(f"output_level NOT explained: gpu {g!r}, own audio's mean square {own!r}, oracle {o!r}")
+            return False
         if field == "fm_pcm":
             # PCM more than 1 LSB apart: the GPU's PCM must be exactly scaleclip of the GPU's own audio, and the audio is
             # then judged as "fm_audio" below
@@ -303,7 +316,7 @@ def main():
                 quiet += ref.quiet
                 near_thr += ref.snr
                 cancel += ref.bbp
-                fm0 += getattr(ref, "fm0", 0) + getattr(ref, "fma", 0)
+                fm0 += getattr(ref, "fm0", 0) + getattr(ref, "fma", 0) + getattr(ref, "lvl", 0)
                 print(f"[{k}] ok* {tag}: every other comparison inside its bar; judged against float64:", flush=True)
                 for line in ref.log:
                     print("       " + line, flush=True)
@@ -316,7 +329,7 @@ def main():
                 print("       " + line, flush=True)
             print(traceback.format_exc(limit=2), flush=True)
     print(f"{cases} cases, {bad} bad; deviations judged against an independent float64 evaluation and found to be the reference "
-          f"arithmetic's own: {explained} n0, {near_thr} snr, {quiet} baseband, {cancel} bb_power, {fm0} FM audio (signed zero at a squelch opening, or a weak flat channel judged against float64); {time.time() - t0:.0f} s")
+          f"arithmetic's own: {explained} n0, {near_thr} snr, {quiet} baseband, {cancel} bb_power, {fm0} FM audio (signed zero at a squelch opening, a weak flat channel judged against float64, or a small block's output_level against its own audio); {time.time() - t0:.0f} s")
     return 1 if bad else 0
 
 

@@ -118,6 +118,34 @@ def hackrf_case(rng):
     return what, e
 
 
+def funcube_f64(buf, blocksize, nblocks, rate, imbalance0=1.0):
+    """funcube.c:364-428 in float64: the values round() is applied to (funcube.c:390-391), in LSB, interleaved I, Q"""
+    SHRT_MAX = 32767.0
+    dc, imb, sinphi = 0j, float(imbalance0), 0.0
+    out = np.empty(2 * blocksize * nblocks, np.float64)
+    for b in range(nblocks):
+        gain_q, gain_i = np.sqrt(0.5 * (1 + imb)), np.sqrt(0.5 * (1 + 1.0 / imb))
+        secphi = 1 / np.sqrt(1 - sinphi * sinphi)
+        tanphi = sinphi * secphi
+        seg = buf[2 * b * blocksize:2 * (b + 1) * blocksize].astype(np.float64) / SHRT_MAX
+        samp = seg[0::2] + 1j * seg[1::2]
+        samp_sum = samp.sum()
+        samp = samp - dc
+        re, im = samp.real, samp.imag
+        i_energy, q_energy = float((re * re).sum()), float((im * im).sum())
+        re, im = re * gain_i, im * gain_q
+        dotprod = float((re * im).sum())
+        im = secphi * im - tanphi * re
+        out[2 * b * blocksize:2 * (b + 1) * blocksize:2] = re * SHRT_MAX
+        out[2 * b * blocksize + 1:2 * (b + 1) * blocksize:2] = im * SHRT_MAX
+        dc += 1.0e-6 * (samp_sum - blocksize * dc)
+        be = i_energy + q_energy
+        if be > 0:
+            imb += rate * (i_energy / q_energy - imb)
+            sinphi += rate * (2 * dotprod / be - sinphi)
+    return out
+
+
 def funcube_case(rng):
     blocksize = int(rng.choice([16, 240, 1000, 4800]))
     nblocks = int(rng.integers(1, 40))
@@ -129,7 +157,16 @@ def funcube_case(rng):
     d = np.abs(got.byteswap().astype(np.int32) - ref.byteswap().astype(np.int32))
     what = f"funcube blocksize={blocksize} blocks={nblocks} rate={rate:.1e}"
     # (words that sit on a rounding tie of round(), funcube.c:390-391: at most 2 per thousand, or 2 in a short run)
-    assert d.max() <= 1 and (d > 0).sum() <= max(2, 2e-3 * d.size), f"{what}: int16 output differs by {d.max()}, {(d > 0).sum()} of {d.size} words"
+    if not (d.max() <= 1 and (d > 0).sum() <= max(2, 2e-3 * d.size)):
+        # more words off than the usual share: each of them must then BE a rounding tie -- the value round() is applied to,
+        # from a float64 evaluation of the whole run, within 0.05 LSB of a half-integer (fp32 against float64 moves it by
+        # ~0.01) -- and off by one only.  (One word in ten lies that close by chance; all of them do not.)
+        v = funcube_f64(buf, blocksize, nblocks, rate)
+        off = np.flatnonzero(d > 0)
+        frac = np.abs(v[off] - np.floor(v[off]) - 0.5)
+        assert d.max() <= 1 and float(frac.max()) <= 0.05, (f"{what}: int16 output differs by {d.max()}, {(d > 0).sum()} of {d.size} words; "
+                                                             f"farthest from a rounding tie {float(frac.max()):.3f} LSB")
+        REFEREED.append(f"{what}: {off.size} of {d.size} words off by one, every one within {float(frac.max()):.3f} LSB of a rounding tie in float64")
     check_state(st_g, orc.fe_fields(st_o), what)
     return what, float((d > 0).mean())
 
