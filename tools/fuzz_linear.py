@@ -90,6 +90,10 @@ def run_case(rng, k, ties):
                     ga, gp = g_aud[c][sl], g_pcm[c][sl]
                     if call == 0 and b == 0:  # start-up on amplified round-off (see the fixed test)
                         ga, gp, audio = ga[(2400 // D) * nch:], gp[(2400 // D) * nch:], audio[(2400 // D) * nch:]
+                    if kw["demod"] == "am":
+                        # am.c:56-59,76-85: the same attack / hang / recover AGC on the carrier estimate, with the rate given
+                        # in dB/s and the hang in seconds (times the output rate: am.c:80): the tie tests below apply
+                        kw = dict(kw, agc=1, recovery_rate=float(10 ** ((kw["recovery_rate"] * D / FS) / 20)), hangtime=kw["hangtime"] * FS / D)
                     scale = max(float(np.abs(audio).max()), 1e-6)
                     err = float(np.abs(ga - audio).max()) / scale
                     worst = max(worst, err)

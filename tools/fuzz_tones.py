@@ -70,7 +70,12 @@ def run_case(rng):
                     digits += b["digit"] != ""
                     assert (a["low_index"], a["high_index"]) == (b["low_index"], b["high_index"]), f"session {s}: DTMF indices {a} vs {b}"
                     for k in ("low_snr", "high_snr"):
-                        assert (np.isnan(a[k]) and np.isnan(b[k])) or abs(a[k] - b[k]) <= 1e-3 * abs(b[k]), f"session {s}: {k} {a} vs {b}"
+                        # pl.c:395-410: snr = max / (total - max).  The subtraction cancels: one fp32 rounding of either energy
+                        # (6e-8) moves the quotient by (snr + 1) times that, on the reference's side as on the GPU's -- at
+                        # snr 2e4 the reference's own value is only good to 2e-3.  The bar follows the formula's condition
+                        # number (two roundings a side); it is 1e-3 up to snr ~ 1e3, where the digits are decided (snr >= 10).
+                        tol = 1e-3 + 2.5e-7 * abs(b[k])
+                        assert (np.isnan(a[k]) and np.isnan(b[k])) or abs(a[k] - b[k]) <= tol * abs(b[k]), f"session {s}: {k} {a} vs {b}"
                 npl += len(pl)
                 ndt += len(dt)
             pos += nw
