@@ -40,11 +40,16 @@ def stream(rng, s, nblocks):
     return synth.pcm_be(x), frames
 
 
-def _compare(s, pos, gb, gframes, st, bo, fo, ost, ties, allow_silence_tie):
-    """the GPU's bit records, frames and counters of one launch against one oracle session's; raises AssertionError"""
+def _compare(s, pos, gb, gframes, st, bo, fo, ost, ties, allow_silence_tie, loose=None):
+    """the GPU's bit records, frames and counters of one launch against one oracle session's; raises AssertionError.
+    loose: the set of sessions whose two bit clocks run one sample apart after a knife edge (below): for those the bit
+    times are held to +-1 sample, the sampled values are not compared, frames and counters are, exactly."""
     gs, os_ = [int(v) for v in gb["sample"]], [b[0] for b in bo]
     bits_tied = False
-    if gs != os_:
+    if loose is not None and s in loose:
+        assert len(gs) == len(os_) and all(abs(a - b) <= 1 for a, b in zip(gs, os_)), f"session {s} block {pos}: clocks more than a sample apart after a knife edge"
+        bits_tied = True
+    elif gs != os_:
         i = next((j for j in range(min(len(gs), len(os_))) if gs[j] != os_[j]), min(len(gs), len(os_)))
         # The bit clock steps on the SIGN of the sampled value: in the silence before a transmission that value is
         # round-off (1e-8 of the signal to come) and its sign a coin toss on both sides.  Verified, not assumed: the
@@ -62,6 +67,15 @@ def _compare(s, pos, gb, gframes, st, bo, fo, ost, ties, allow_silence_tie):
             keep[i - 1:rejoin] = False
             if keep.any():
                 assert np.abs(gc[keep] - oc[keep]).max() <= 1e-4 * peak, f"session {s} block {pos}: cur_val"
+            bits_tied = True
+        elif (allow_silence_tie and loose is not None and i >= 1 and len(gs) == len(os_) and gc[i - 1] * oc[i - 1] <= 0
+              and max(abs(gc[i - 1]), abs(oc[i - 1])) <= 1e-6 * peak and all(abs(a - b) <= 1 for a, b in zip(gs[i:], os_[i:]))):
+            # the same knife edge inside a signal: the sampled value is zero to the last bit (seen: 0.0 against 9.5e-07 of a
+            # peak of 68 -- the two sides add the same 40 products in a different order), and here the clocks do not
+            # rejoin at once: they run one sample apart until the loop pulls both to the same place.  Held from here on
+            # to +-1 sample; frames and counters must still agree exactly.
+            ties.append(f"session {s} block {pos}: bit clock knife edge inside a signal at bit {i - 1} (values {gc[i - 1]:.2e} / {oc[i - 1]:.2e} of a peak {peak:.2e}); clocks one sample apart from there")
+            loose.add(s)
             bits_tied = True
         else:
             raise AssertionError(f"session {s} block {pos}: bit times differ: {len(gs)} vs {len(os_)} bits, first difference at bit {i}: "
@@ -86,6 +100,7 @@ def run_case(rng, ties):
     # referee for bit clocks that part ways (below)
     reps = [orc.AfskSession() for _ in range(nsess)]
     follows_replay = set()
+    loose = set()
     decoded = total = 0
     try:
         pos = 0
@@ -110,7 +125,7 @@ def run_case(rng, ties):
                 gb, gframes, st = dev.bits(s), dev.frames(s), dev.status(s)
                 if s not in follows_replay:
                     try:
-                        _compare(s, pos, gb, gframes, st, bo, fo, ors[s].st, ties, True)
+                        _compare(s, pos, gb, gframes, st, bo, fo, ors[s].st, ties, True, loose)
                     except AssertionError as e:
                         # The clock steps by +-1 sample on the sign of (cur - last) * mid_val (packet.c:469), and mid_val is
                         # a difference of two energies that passes through zero at every mark/space transition: a sample

@@ -172,7 +172,7 @@ class Referee:
                     if ctx["worst"] > 0 and rg <= 1.5 * ro + 1e-7 and (eg[beyond] <= 3 * max(float(eo.max()), 1e-7)).all():
                         self.fma = getattr(self, "fma", 0) + 1
                         self.log.append(f"fm_audio ch {ctx['ch']} block {ctx['block']}: against the float64 baseband's audio: gpu rms {rg:.2e} "
-                                        f"(worst of the {beyond.size} samples beyond the bar {float(eg[beyond].max()):.2e}), oracle rms {ro:.2e} (worst {float(eo.max()):.2e}); "
+                                        f"(worst of the {beyond.size} samples beyond the bar {float(eg[beyond].max()) if beyond.size else 0.0:.2e}), oracle rms {ro:.2e} (worst {float(eo.max()):.2e}); "
                                         f"|y| there {float(np.abs(yo[1:][beyond]).min()):.2e} of a block peak {float(np.abs(yo).max()):.2e}")
                         return True
                     # Second decomposition (as for snr): the GPU's audio against the float64 discriminator of the baseband the
@@ -185,7 +185,7 @@ class Referee:
                         self.fma = getattr(self, "fma", 0) + 1
                         self.log.append(f"fm_audio ch {ctx['ch']} block {ctx['block']}: gpu audio is the float64 discriminator of the GPU's own baseband to "
                                         f"{float(e_own.max()):.1e} (gain {gain:.4f}); against the float64 baseband's audio gpu rms {rg:.2e}, oracle rms {ro:.2e}; the "
-                                        f"{beyond.size} samples beyond the bar sit on |y| {float(np.abs(yo[1:][beyond]).min()):.2e} of a block peak {float(np.abs(yo).max()):.2e}")
+                                        f"{beyond.size} samples beyond the bar sit on |y| {float(np.abs(yo[1:][beyond]).min()) if beyond.size else float('nan'):.2e} of a block peak {float(np.abs(yo).max()):.2e}")
                         return True
                     self.log.append(f"fm_audio: against float64: gpu rms {rg:.2e} oracle rms {ro:.2e}, gpu at the samples beyond the bar {eg[beyond]}, oracle worst {float(eo.max()):.2e}; against its own baseband's discriminator {float(e_own.max()):.2e}")
             self.log.append("fm_audio NOT explained: " + ctx["msg"])
