@@ -809,24 +809,37 @@ static int enqueue_back(kh_bank *b, hipStream_t st, unsigned int nblocks, bool p
     return -1;
   if (prof) hipEventRecord(b->ev[4], st);
   int taken = 0;
-  if (launch_filter_output(st, b->d_spec[sp], b->spec_stride, N, 0, b->d_chans, b->d_resp, b->ND, b->olen, b->d_bb,
-                           b->bb_stride, nblocks, C,
-                           FmFront{b->n_fm ? b->d_fmstat : nullptr, b->d_fmwork, b->d_fmcarry, b->d_ddesc, b->T, b->bb_stride,
-                                   b->keep_baseband},
-                           1, ride ? &z : nullptr, &taken))
+  // round 3's back half (kh_chan2 + kh_fm_snr_lanes + kh_fm_demod2) for N_dec = 512 / 1024; KA9Q_HIP_BACK2=0 and every
+  // other shape take round 2's kernels
+  bool const back2 = fm2_usable(b->ND, b->olen, (int)nblocks) != 0;
+  if (back2) {
+    if (launch_chan2(st, b->d_spec[sp], b->spec_stride, N, b->d_chans, b->d_resp, b->ND, b->olen, b->d_bb, b->bb_stride, nblocks, C,
+                     b->n_fm ? b->d_fmstat : nullptr, b->T, ride ? &z : nullptr))
+      return -1;
+    taken = ride;
+  } else if (launch_filter_output(st, b->d_spec[sp], b->spec_stride, N, 0, b->d_chans, b->d_resp, b->ND, b->olen, b->d_bb,
+                                  b->bb_stride, nblocks, C,
+                                  FmFront{b->n_fm ? b->d_fmstat : nullptr, b->d_fmwork, b->d_fmcarry, b->d_ddesc, b->T, b->bb_stride,
+                                          b->keep_baseband},
+                                  1, ride ? &z : nullptr, &taken))
     return -1;
   // kh_n0_final's work (one workgroup per input) rides in the FM finish launch when there is one of the wave form
   N0FinalArgs nf;
-  bool const ride_final = ride && taken && b->n_fm > 0 && fm_finish_wave_usable(b->olen, nblocks);
+  bool const ride_final = ride && taken && b->n_fm > 0 && (back2 || fm_finish_wave_usable(b->olen, nblocks));
   if (ride && launch_n0(st, n0spec, b->spec_stride, N, b->cfg.samprate, plan, b->d_energy[sp], echunks, L, b->d_n0state,
                         b->d_n0acc[sp], b->d_istatus, nblocks, P, taken, ride_final ? &nf : nullptr, dsync))
     return -1;
   if (prof) hipEventRecord(b->ev[5], st);
+  if (back2 && b->n_fm > 0 &&
+      launch_fm2(st, b->d_bb, b->bb_stride, b->olen, nblocks, b->d_ddesc, b->d_dstate, b->keep_audio ? b->d_audio : nullptr, b->d_pcm,
+                 b->pcm_stride, b->cfg.pcm_big_endian, b->d_status, b->T, b->d_lists, b->n_fm, b->d_fmstat, b->d_decaypow,
+                 b->fm_parity, ride_final ? &nf : nullptr))
+    return -1;
   if (launch_demod(st, b->d_bb, b->bb_stride, b->olen, nblocks, C, b->d_ddesc, b->d_dstate,
                    b->keep_audio ? b->d_audio : nullptr, b->d_pcm, b->pcm_stride, b->cfg.pcm_big_endian, b->d_status,
-                   b->T, b->d_lists, b->n_fm, b->d_lists + C, b->n_lin, b->d_lists + 2 * C, b->n_am,
-                   FmScratch{b->d_fmstat, b->d_fmwork, b->d_fmcarry, b->d_decaypow, b->fm_parity}, ride_final ? &nf : nullptr,
-                   b->n_lin_nopll))
+                   b->T, b->d_lists, back2 ? 0 : b->n_fm, b->d_lists + C, b->n_lin, b->d_lists + 2 * C, b->n_am,
+                   FmScratch{b->d_fmstat, b->d_fmwork, b->d_fmcarry, b->d_decaypow, b->fm_parity},
+                   (ride_final && !back2) ? &nf : nullptr, b->n_lin_nopll))
     return -1;
   if (b->rtp && launch_rtp_plan(st, b->d_pcm, b->pcm_stride, b->olen, nblocks, C, b->d_ddesc, b->d_rtp, b->rtp_stride,
                                 b->d_rtpstate))

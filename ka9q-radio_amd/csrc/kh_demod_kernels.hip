@@ -101,65 +101,7 @@ __global__ __launch_bounds__(256) void kh_n0_pass1(N0Pass1Args Z) {
   n0_pass1_body(Z, blockIdx.x, sh);
 }
 
-// one workgroup per input, one wave per block (16 waves: 16 blocks at a time; every lane issues all of its loads
-// before the first shuffle, so a block costs one memory round trip), then lane 0 applies radio.c:197-202 block by
-// block from LDS
-constexpr int N0_FT = 1024;
-// one workgroup (any multiple of 64 threads) per input i; sv/se hold N0_MAXB floats each.  Every wave takes blocks
-// wave, wave + nwaves, ...; the loads of four blocks are issued before the first shuffle.
-__device__ __forceinline__ void n0_final_body(N0FinalArgs const &Z, int i, float *sv, float *se) {
-  int const lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
-  int const nblocks = Z.nblocks;
-  const float *part1 = Z.part + (size_t)Z.ninputs * nblocks * N0_SLOTS;
-  constexpr int U = 4;
-  for (int b0 = wave; b0 < nblocks; b0 += U * nwaves) {
-    float es[U], s1[U], c1[U];
-#pragma unroll
-    for (int u = 0; u < U; u++) {
-      int const b = b0 + u * nwaves;
-      es[u] = s1[u] = c1[u] = 0.f;
-      if (b < nblocks) {
-        size_t const pt = (size_t)i * nblocks + b;
-        const float *e = Z.energy_part + pt * Z.echunks;
-        for (int k = lane; k < Z.echunks; k += 64) es[u] += e[k];
-        if (Z.have_n0 && Z.valid) {
-          float2 const sc = reinterpret_cast<const float2 *>(part1 + pt * (2 * N0_GX))[lane]; // N0_GX == 64: one per lane
-          s1[u] = sc.x;
-          c1[u] = sc.y;
-        }
-      }
-    }
-#pragma unroll
-    for (int u = 0; u < U; u++) {
-      int const b = b0 + u * nwaves;
-      float const e = wave_sum(es[u]), s = wave_sum(s1[u]), c = wave_sum(c1[u]);
-      float v = NAN;
-      if (Z.have_n0) v = Z.valid ? (s / c) / ((float)Z.N * Z.samprate) : 0.f; // radio.c:433-435 ("Can this happen?"), 461, 464
-      if (lane == 0 && b < nblocks) {
-        se[b] = e / Z.L; // radio.c:197
-        sv[b] = v;
-      }
-    }
-  }
-  __syncthreads();
-  if (threadIdx.x == 0 && Z.have_n0) {
-    float n0 = Z.n0_state[i];
-    for (int b = 0; b < nblocks; b++) {
-      float const v = sv[b];
-      if (!isnan(n0))
-        n0 = (float)((double)n0 + .005 * (double)(v - n0));
-      else
-        n0 = v;
-      sv[b] = n0;
-    }
-    Z.n0_state[i] = n0;
-  }
-  __syncthreads();
-  for (int b = threadIdx.x; b < nblocks; b += blockDim.x) {
-    Z.status[(size_t)i * nblocks + b].if_power = se[b];
-    Z.status[(size_t)i * nblocks + b].n0 = sv[b];
-  }
-}
+// (n0_final_body: kh_n0.cuh)
 __global__ __launch_bounds__(N0_FT) void kh_n0_final(N0FinalArgs Z) {
   __shared__ float sv[N0_MAXB], se[N0_MAXB];
   n0_final_body(Z, blockIdx.x, sv, se);
@@ -217,18 +159,7 @@ int launch_n0(hipStream_t st, const float2 *spec, size_t spec_in_stride, int N, 
   return KH_HIP(hipGetLastError()) ? 0 : -1;
 }
 
-// ================================================================ scaleclip: audio.c:22-28
-__device__ __forceinline__ short scaleclip(float x) {
-  if (x >= 1.0f) return 32767;
-  if (x <= -1.0f) return -32768;
-  return (short)(32767 * x); // truncation toward zero
-}
-__device__ __forceinline__ short pcm_word(float x, int big_endian) {
-  short const v = scaleclip(x);
-  if (!big_endian) return v;
-  unsigned short const u = (unsigned short)v;
-  return (short)(unsigned short)((u << 8) | (u >> 8)); // htons, audio.c:50,101
-}
+// (scaleclip / pcm_word, audio.c:22-28,50,101: kh_fm.cuh)
 
 // ================================================================ FM: fm.c:43-139 in two parallel steps
 //  (1) kh_filter_out's epilogue (fm_front, kh_fm.cuh), one workgroup per (channel, block), while the block is still

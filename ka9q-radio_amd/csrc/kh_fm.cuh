@@ -119,6 +119,19 @@ __device__ __forceinline__ float fast_atan2f(float y, float x) {
   return copysignf(r, y);
 }
 
+// scaleclip: audio.c:22-28
+__device__ __forceinline__ short scaleclip(float x) {
+  if (x >= 1.0f) return 32767;
+  if (x <= -1.0f) return -32768;
+  return (short)(32767 * x); // truncation toward zero
+}
+__device__ __forceinline__ short pcm_word(float x, int big_endian) {
+  short const v = scaleclip(x);
+  if (!big_endian) return v;
+  unsigned short const u = (unsigned short)v;
+  return (short)(unsigned short)((u << 8) | (u >> 8)); // htons, audio.c:50,101
+}
+
 // block-wide sum for workgroups of NT threads (NT a multiple of 64, <= 1024); `red` holds NT/64 floats.
 // Every thread gets the total.  Two barriers.
 template <int NT>

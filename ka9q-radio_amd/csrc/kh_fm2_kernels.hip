@@ -1,0 +1,406 @@
+// kh_fm2_kernels.hip -- demod_fm (fm.c:43-139) behind kh_chan2: the Rice-corrected SNR one lane per (channel, block),
+// then one workgroup per channel that only demodulates the blocks whose squelch is open.
+//
+// Reference behaviour restated here (citations into the reference tree):
+//   fm_snr                 fm.c:190-205 (the fixed-point iteration; xi from kh_fm.cuh's polynomial pieces)
+//   squelch                fm.c:73-78 (open for two blocks after the SNR last exceeded 4), 123 (state zeroed when closed)
+//   discriminator          fm.c:85-93 (conjugate product, cargf, amplitude weight cabsf(p) / fm_variance clipped to 1)
+//   peak deviation         fm.c:97-102, 114-121 (order dependent), de-emphasis fm.c:105-111, closed squelch fm.c:124-132
+//   output level           fm.c:135-138, scaleclip audio.c:22-28
+//
+// Why the split (profiles/r03_base_*_sq.txt): the channel wavefronts of round 2 ran discriminator, integrator scan and
+// fm_snr's iteration for every (channel, block) -- ~1000 vector instructions a pair -- although a bank is mostly idle
+// channels whose squelch is closed, and fm_snr ran wave-uniform (one value per 64 lanes' issue slots) exactly where it
+// is slowest (amplitude of pure noise: avg^2/var sits at fm_snr's threshold pi/(4-pi); 10 rounds on average, 65 at most).
+//   kh_fm_snr_lanes   a lane per (channel, block): 64 iterations share a wavefront's issue slots
+//   kh_fm_demod2      a workgroup per channel, G = olen/8 lanes per block.  Closed blocks cost the squelch logic and
+//                     the decaying carry (fm.c:124-132); open blocks read their baseband, run fm.c:85-111 with the
+//                     integrator started from zero, hand the block's carry-out through LDS, and add lastaudio's
+//                     contribution c_in decay^n (fm.c:110-111 is linear in lastaudio) after one barrier.
+// Roofline: HBM; algorithmic bytes per open (channel, block): 8*olen baseband read + 2*olen PCM written.
+#include "kh_internal.h"
+#include "kh_fft.cuh"
+#include "kh_fm.cuh"
+#include "kh_n0.cuh"
+#include "../../include/ka9q_hip.h"
+#include <cstdlib>
+
+namespace kh {
+
+// fm_snr (fm.c:190-205) with a different argument in every lane: kh_fm.cuh's fm_snr() without the scalar registers.
+// Same polynomial pieces, same iteration and stopping rule, hence the same value for the same r.
+static __device__ double fm_snr_lane(double r) {
+  double thetasq = r;
+  double othetasq = r + 10;
+  if (r <= M_PI / (4 - M_PI)) return 0;
+  if (r > 100) return r;
+  double const r1 = 1 + r;
+  double lo = 1.0, hi = 0.0, mid = 0.0, scale = 0.0, c[KH_XI_DEG + 1]; // empty segment: the first round loads one
+#pragma unroll
+  for (int k = 0; k <= KH_XI_DEG; k++) c[k] = 0.0;
+  int guard = 0; // the reference loop has no bound; NaN input falls through both tests above and exits here
+  while (fabs(thetasq - othetasq) > .001 && guard++ < 10000) {
+    othetasq = thetasq;
+    if (!(thetasq >= 0.0 && thetasq <= 100.0)) {
+      thetasq = fm_xi(thetasq) * r1 - 2;
+      continue;
+    }
+    if (!(thetasq >= lo && thetasq < hi)) {
+      int g = (int)(thetasq * (1.0 / KH_XI_GRID));
+      g = g < KH_XI_NLUT ? g : KH_XI_NLUT - 1;
+      int const seg = kh_xi_lut[g];
+      double const e1 = kh_xi_edges[seg + 1];
+      lo = kh_xi_edges[seg];
+      hi = seg == KH_XI_SEGS - 1 ? 101.0 : e1; // thetasq == 100 belongs to the last segment
+      mid = 0.5 * (lo + e1);
+      scale = 2.0 / (e1 - lo);
+#pragma unroll
+      for (int k = 0; k <= KH_XI_DEG; k++) c[k] = kh_xi_coeffs[seg][k];
+    }
+    double const u = (thetasq - mid) * scale;
+    double const u2 = u * u, u4 = u2 * u2, u8 = u4 * u4;
+    double const p01 = fma(c[1], u, c[0]), p23 = fma(c[3], u, c[2]), p45 = fma(c[5], u, c[4]);
+    double const p67 = fma(c[7], u, c[6]), p89 = fma(c[9], u, c[8]), pab = fma(c[11], u, c[10]);
+    double const q0 = fma(p23, u2, p01), q1 = fma(p67, u2, p45), q2 = fma(pab, u2, p89);
+    double const xi = fma(q2, u8, fma(q1, u4, q0));
+    thetasq = xi * r1 - 2;
+  }
+  return thetasq;
+}
+
+// stat[ch][b].snr holds avg^2 / variance on entry (kh_chan2) and fmaxf(0, fm_snr(.)) on return (fm.c:69-70).
+// Workgroups beyond nsnr_wg (if any) are kh_n0_final's work, one per input.
+__global__ __launch_bounds__(256) void kh_fm_snr_lanes(FmBlockStat *__restrict__ stat, int stat_stride, const int *__restrict__ list,
+                                                       int n_fm, int nblocks, unsigned magic, int nsnr_wg, N0FinalArgs Z) {
+  __shared__ float sv[N0_MAXB], se[N0_MAXB];
+  if ((int)blockIdx.x >= nsnr_wg) {
+    n0_final_body(Z, blockIdx.x - nsnr_wg, sv, se);
+    return;
+  }
+  int const q = blockIdx.x * 256 + threadIdx.x;
+  if (q >= n_fm * nblocks) return;
+  int const ci = magic ? (int)__umulhi((unsigned)q, magic) : q, b = q - ci * nblocks;
+  FmBlockStat *s = stat + (size_t)list[ci] * stat_stride + b;
+  s->snr = fmaxf(0.0f, (float)fm_snr_lane((double)s->snr));
+}
+
+struct Fm2Args {
+  int nblocks;
+  const DemodDesc *descs;
+  DemodState *states;
+  int par;
+  const FmBlockStat *stat;
+  int stat_stride;
+  const float2 *bb;
+  size_t bb_stride;
+  const double *decay_pow;
+  float *audio;
+  int16_t *pcm;
+  size_t pcm_stride;
+  int big_endian;
+  kh_status *status;
+  int status_stride;
+  const int *list;
+};
+
+template <int G>
+__device__ __forceinline__ float fm2_group_sum(float v) {
+#pragma unroll
+  for (int o = G / 2; o > 0; o >>= 1) v += __shfl_xor(v, o, G);
+  return v;
+}
+
+constexpr int FM2_MAXBP = 16; // blocks per pass: at most 16 wavefronts per workgroup
+// one workgroup per FM channel; blockDim.x / G groups of G lanes, group `bl` of a pass takes block b0 + bl
+template <int G>
+__global__ __launch_bounds__(1024) void kh_fm_demod2(Fm2Args F) {
+  constexpr int K = 8, OLEN = K * G, PPW = 64 / G;
+  static_assert(G == 32 || G == 64, "olen = 256 or 512");
+  __shared__ double shB[2][FM2_MAXBP];
+  int const lane64 = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  int const l = lane64 % G, bl = wave * PPW + lane64 / G;
+  int const BP = (blockDim.x >> 6) * PPW;
+  int const ch = F.list[blockIdx.x];
+  const DemodDesc *dd = F.descs + ch;
+  DemodState *st = F.states + ch;
+  const FmBlockStat *fs = F.stat + (size_t)ch * F.stat_stride;
+  int const par = F.par, nblocks = F.nblocks;
+  int const flat = dd->flat;
+  float const dsamprate = dd->dsamprate, gain = dd->fm_gain;
+  int const so_in = st->fm_squelch_open[par];
+  float2 const state_in = st->fm_state[par];
+  float const lastaudio_in = st->fm_lastaudio[par];
+  double const Ablk = F.decay_pow[OLEN];
+  double const dpl = F.decay_pow[K * l]; // decay^(K l)
+  const float2 *bbc = F.bb + (size_t)ch * F.bb_stride;
+  double c_pass = (double)lastaudio_in; // lastaudio on entry to the pass's first block
+  int pp = 0;
+  for (int b0 = 0; b0 < nblocks; b0 += BP, pp ^= 1) {
+    int const b = b0 + bl;
+    bool const have = b < nblocks;
+    // ---- fm.c:73-78 in closed form (fm_counter_after, kh_demod_kernels.hip): the counter after block j is 1 if snr_j > 4,
+    // else max(so_in - 1, 0) for j = 0 and 0 for j >= 1; a block demodulates iff snr > 4 or the counter before it is positive
+    float const snr_b = have ? fs[b].snr : 0.f;
+    float const snr_p = (have && b >= 1) ? fs[b - 1].snr : 0.f;
+    float const snr_pp = (have && b >= 2) ? fs[b - 2].snr : 0.f;
+    int const dec_in = so_in - 1 > 0 ? so_in - 1 : 0;
+    int const cnt_pp = b >= 2 ? (snr_pp > 4.f ? 1 : (b == 2 ? dec_in : 0)) : so_in; // counter before block b - 1
+    int const cnt_p = b >= 1 ? (snr_p > 4.f ? 1 : (b == 1 ? dec_in : 0)) : so_in;  // counter before block b
+    bool const open = have && (snr_b > 4.f || cnt_p > 0);
+    bool const open_p = b >= 1 && (snr_p > 4.f || cnt_pp > 0);
+    int const so = snr_b > 4.f ? 1 : (b == 0 ? dec_in : 0);
+
+    float2 y[K];
+    float ang[K], wgt[K];
+    double x[K];
+    double cin0 = 0.0, Bsum = 0.0;
+    float angsum = 0.f;
+    float2 ylast = make_float2(0.f, 0.f);
+    if (open) {
+      const float4 *yi = reinterpret_cast<const float4 *>(bbc + (size_t)b * OLEN + K * l);
+#pragma unroll
+      for (int j = 0; j < K; j += 2) {
+        float4 const t = yi[j / 2];
+        y[j] = make_float2(t.x, t.y);
+        y[j + 1] = make_float2(t.z, t.w);
+      }
+      // fm.c:86-87: the sample before; block 0: the carried state; a closed block before leaves 0 (fm.c:123)
+      float2 prev = make_float2(__shfl_up(y[K - 1].x, 1, G), __shfl_up(y[K - 1].y, 1, G));
+      if (l == 0) {
+        prev = make_float2(0.f, 0.f);
+        if (b == 0)
+          prev = state_in;
+        else if (open_p)
+          prev = bbc[(size_t)b * OLEN - 1];
+      }
+      ylast = make_float2(__shfl(y[K - 1].x, G - 1, G), __shfl(y[K - 1].y, G - 1, G));
+      float const inv_var = 1.f / fs[b].variance;
+#pragma unroll
+      for (int j = 0; j < K; j++) {
+        float2 const p = cmulc(y[j], j ? y[j - 1] : prev);
+        float const a = fast_atan2f(p.y, p.x);                                 // cargf, fm.c:89
+        float w = __builtin_amdgcn_sqrtf(p.x * p.x + p.y * p.y) * inv_var;     // cabsf(p) / fm_variance, fm.c:91
+        if (w > 1) w = 1;
+        ang[j] = a;
+        wgt[j] = w;
+        angsum += a;
+      }
+      angsum = fm2_group_sum<G>(angsum);
+      if (!flat) {
+        double B = 0.0; // this lane's chunk as the map carry_out = decay^K carry_in + B
+#pragma unroll
+        for (int j = 0; j < K; j++) {
+          x[j] = (double)ang[j] * .114 * (double)gain * (double)wgt[j]; // fm.c:110
+          B = (B + x[j]) * FM_DECAY;
+        }
+        // inclusive scan over the group's lanes; every lane's multiplier is decay^K, so at distance o it is decay^(K o)
+        double Bi = B;
+        double Apow = FM_DECAY_K8;
+        static_assert(K == 8, "FM_DECAY_K8 is decay^8");
+#pragma unroll
+        for (int o = 1; o < G; o <<= 1) {
+          double const Bp = __shfl_up(Bi, o, G);
+          if (l >= o) Bi = fma(Apow, Bp, Bi);
+          Apow *= Apow;
+        }
+        cin0 = __shfl_up(Bi, 1, G); // lastaudio entering this lane's chunk for a zero carry into the block
+        if (l == 0) cin0 = 0.0;
+        Bsum = __shfl(Bi, G - 1, G);
+      }
+    }
+    if (l == 0 && bl < FM2_MAXBP) shB[pp][bl] = Bsum;
+    __syncthreads();
+    // lastaudio on entry to this block: the blocks of the pass before it, each c <- decay^olen c + B (fm.c:110-111,130)
+    double c_in = c_pass, c_run = c_pass;
+    if (!flat) {
+      for (int j = 0; j < BP; j++) {
+        if (j == bl) c_in = c_run;
+        c_run = fma(Ablk, c_run, shB[pp][j]);
+      }
+      c_pass = c_run;
+    }
+    if (!have) continue; // (every thread still meets every barrier: the loop bounds are uniform)
+
+    // ---- fm.c:105-111 (open) / 124-132 (closed): audio, scaleclip, output level
+    float s1[K], la[K];
+    float lv = 0.f;
+    if (open) {
+      if (flat) {
+#pragma unroll
+        for (int j = 0; j < K; j++) s1[j] = ang[j] * gain; // fm.c:105
+      } else {
+        double cin = fma(c_in, dpl, cin0);
+#pragma unroll
+        for (int j = 0; j < K; j++) {
+          cin += x[j];     // samples[n] = lastaudio += ...
+          s1[j] = (float)cin;
+          cin *= FM_DECAY; // lastaudio *= 0.99376949
+        }
+      }
+    } else {
+      double v = c_in * dpl;
+#pragma unroll
+      for (int j = 0; j < K; j++) {
+        s1[j] = flat ? 0.f : (float)v; // fm.c:124-132: the decaying carry alone
+        v *= FM_DECAY;
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < K; j++) lv += s1[j] * s1[j];
+    size_t const obase = (size_t)b * OLEN + K * l;
+    {
+      int16_t *po = F.pcm + (size_t)ch * F.pcm_stride + obase;
+      unsigned wd[4];
+#pragma unroll
+      for (int u = 0; u < 4; u++)
+        wd[u] = (unsigned)(unsigned short)pcm_word(s1[2 * u], F.big_endian) |
+                ((unsigned)(unsigned short)pcm_word(s1[2 * u + 1], F.big_endian) << 16);
+      *reinterpret_cast<uint4 *>(po) = make_uint4(wd[0], wd[1], wd[2], wd[3]);
+    }
+    if (F.audio) {
+      float4 *ao = reinterpret_cast<float4 *>(F.audio + (size_t)ch * F.pcm_stride + obase);
+      ao[0] = make_float4(s1[0], s1[1], s1[2], s1[3]);
+      ao[1] = make_float4(s1[4], s1[5], s1[6], s1[7]);
+    }
+    float const level = fm2_group_sum<G>(lv) / OLEN; // fm.c:135-138
+
+    // ---- fm.c:97-102, order dependent: pdev_pos is a running maximum; pdev_neg moves to ang_k at the first later
+    // sample that is not a new maximum and whose lastaudio is below the current pdev_neg (see fm_finish_wave in
+    // kh_demod_kernels.hip for the relaxation and why its fixed point is the serial result)
+    float pdev_pos = 0.f, pdev_neg = 0.f;
+    if (open) {
+      { // lastaudio when sample n is processed = previous sample * decay (fm.c:110-111); flat: it never changes
+        float const prev_lane = __shfl_up(s1[K - 1], 1, G);
+#pragma unroll
+        for (int j = 0; j < K; j++) {
+          float const sp = j ? s1[j - 1] : prev_lane;
+          la[j] = flat ? (float)c_in : (float)((double)sp * FM_DECAY);
+        }
+      }
+      float lmax = ang[0];
+#pragma unroll
+      for (int j = 1; j < K; j++) lmax = fmaxf(lmax, ang[j]);
+      float inc = lmax; // inclusive prefix maximum over the group's lanes
+#pragma unroll
+      for (int o = 1; o < G; o <<= 1) {
+        float const p = __shfl_up(inc, o, G);
+        if (l >= o) inc = fmaxf(inc, p);
+      }
+      float run = __shfl_up(inc, 1, G);
+      if (l == 0) run = -INFINITY;
+      pdev_pos = __shfl(inc, G - 1, G);
+      float thr[K]; // lastaudio where fm.c:101 is reached, +inf elsewhere
+#pragma unroll
+      for (int j = 0; j < K; j++) {
+        bool const up = ang[j] > run; // fm.c:99: ang > pdev_pos
+        thr[j] = (up || (l == 0 && j == 0)) ? INFINITY : la[j];
+        run = fmaxf(run, ang[j]);
+      }
+      float const c_first = __shfl(ang[0], 0, G); // fm.c:97-98
+      float mlane = INFINITY;
+#pragma unroll
+      for (int j = 0; j < K; j++) mlane = fminf(mlane, thr[j]);
+      float cin = c_first, last_val = c_first;
+      for (int it = 0; it < G; it++) {
+        float c = cin;
+#pragma unroll
+        for (int j = 0; j < K; j++)
+          if (thr[j] < c) c = ang[j];
+        int has = !(cin <= mlane); // this lane's output is its own (not the input handed on)
+        int val = __float_as_int(c);
+        // inclusive scan over the group's lanes of "the nearest lane at or before this one that has a value" in DPP
+        // moves: shifts by 1, 2, 4, 8 inside the rows of 16, lane 15 of rows 0 and 2 into rows 1 and 3, and (G = 64)
+        // lane 31 into the upper half.  Lanes a move does not reach receive has = 0, the identity.
+#define KH_PDEV_STEP(CTRL, ROWS)                                                            \
+        {                                                                                     \
+          int const ph = __builtin_amdgcn_update_dpp(0, has, CTRL, ROWS, 0xf, false);         \
+          int const pv = __builtin_amdgcn_update_dpp(0, val, CTRL, ROWS, 0xf, false);         \
+          val = has ? val : pv;                                                               \
+          has = has ? has : ph;                                                               \
+        }
+        KH_PDEV_STEP(0x111, 0xf) // row_shr:1
+        KH_PDEV_STEP(0x112, 0xf) // row_shr:2
+        KH_PDEV_STEP(0x114, 0xf) // row_shr:4
+        KH_PDEV_STEP(0x118, 0xf) // row_shr:8
+        KH_PDEV_STEP(0x142, 0xa) // row_bcast:15 into rows 1, 3
+        if constexpr (G == 64) KH_PDEV_STEP(0x143, 0xc) // row_bcast:31 into rows 2, 3
+#undef KH_PDEV_STEP
+        int const hp = __builtin_amdgcn_update_dpp(0, has, 0x138, 0xf, 0xf, false); // wave_shr:1
+        int const np_ = __builtin_amdgcn_update_dpp(0, val, 0x138, 0xf, 0xf, false);
+        float const ncin = (hp && l != 0) ? __int_as_float(np_) : c_first;
+        last_val = __shfl(has, G - 1, G) ? __int_as_float(__shfl(val, G - 1, G)) : c_first;
+        bool const changed = __float_as_int(ncin) != __float_as_int(cin);
+        cin = ncin;
+        if (!__builtin_amdgcn_ballot_w64(changed)) break;
+      }
+      pdev_neg = last_val;
+    }
+    if (l == 0) {
+      kh_status r;
+      r.bb_power = fs[b].bb_power;
+      r.snr = snr_b;
+      r.foffset = NAN; // fm.c:116,121 leave both untouched while the squelch is closed
+      r.pdeviation = NAN;
+      if (open) {
+        float const avg_f = angsum / OLEN; // fm.c:96,114
+        r.foffset = (float)((double)(dsamprate * avg_f) * (0.5 * M_1_PI)); // fm.c:116
+        pdev_pos -= avg_f;
+        pdev_neg -= avg_f;
+        r.pdeviation = (float)((double)(dsamprate * fmaxf(pdev_pos, -pdev_neg)) * (0.5 * M_1_PI)); // fm.c:121
+      }
+      r.cphase = 0.f;
+      r.lock_timer = 0.f;
+      r.pll_lock = 0;
+      r.output_level = level;
+      r.agc_gain = NAN;
+      r.squelch_open = so;
+      r.reserved[0] = r.reserved[1] = 0.f;
+      F.status[(size_t)ch * F.status_stride + b] = r;
+      if (b == nblocks - 1) { // state carried to the next launch (fm.c:26,32,33), into the other parity slot
+        double c = c_in;
+        if (!flat) c = fma(Ablk, c_in, Bsum);
+        st->fm_lastaudio[par ^ 1] = (float)c;
+        st->fm_squelch_open[par ^ 1] = so;
+        st->fm_state[par ^ 1] = open ? ylast : make_float2(0.f, 0.f);
+      }
+    }
+  }
+}
+
+int fm2_usable(int ND, int olen, int nblocks) {
+  static int const env = getenv("KA9Q_HIP_BACK2") ? atoi(getenv("KA9Q_HIP_BACK2")) : 1; // A/B switch: 0 = round 2's kernels
+  return env && chan_wave_supported(ND, olen) && nblocks >= 1 && nblocks <= N0_MAXB;
+}
+
+// n0final (may be null): kh_n0_final's work rides in the SNR launch
+int launch_fm2(hipStream_t st, const float2 *baseband, size_t bb_stride, int olen, int nblocks, const DemodDesc *desc,
+               DemodState *state, float *audio, int16_t *pcm, size_t pcm_stride, int pcm_big_endian, void *status,
+               int status_stride, const int *fm_list, int n_fm, FmBlockStat *stat, const double *decay_pow, int parity,
+               const N0FinalArgs *n0final) {
+  if (nblocks <= 0) return 0;
+  if (olen != 256 && olen != 512) {
+    set_error("FM demodulator (workgroup per channel): olen %d unsupported", olen);
+    return -1;
+  }
+  int const npairs = n_fm * nblocks;
+  int const nsnr_wg = (npairs + 255) / 256;
+  N0FinalArgs const Z = n0final ? *n0final : N0FinalArgs{};
+  unsigned const magic = nblocks == 1 ? 0u : (unsigned)(((1ull << 32) + (unsigned)nblocks - 1) / (unsigned)nblocks);
+  if (nsnr_wg + (n0final ? n0final->ninputs : 0) > 0)
+    hipLaunchKernelGGL(kh_fm_snr_lanes, dim3(nsnr_wg + (n0final ? n0final->ninputs : 0)), dim3(256), 0, st, stat, status_stride,
+                       fm_list, n_fm, nblocks, magic, nsnr_wg, Z);
+  if (n_fm > 0) {
+    Fm2Args const F{nblocks, desc, state, parity, stat, status_stride, baseband, bb_stride, decay_pow, audio, pcm, pcm_stride,
+                    pcm_big_endian, static_cast<kh_status *>(status), status_stride, fm_list};
+    int const G = olen / 8, ppw = 64 / G;
+    int nw = (nblocks + ppw - 1) / ppw;
+    if (nw > FM2_MAXBP / ppw) nw = FM2_MAXBP / ppw; // at most 16 blocks per pass
+    if (G == 32)
+      hipLaunchKernelGGL(kh_fm_demod2<32>, dim3(n_fm), dim3(64 * nw), 0, st, F);
+    else
+      hipLaunchKernelGGL(kh_fm_demod2<64>, dim3(n_fm), dim3(64 * nw), 0, st, F);
+  }
+  return KH_HIP(hipGetLastError()) ? 0 : -1;
+}
+
+} // namespace kh

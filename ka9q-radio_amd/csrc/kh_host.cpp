@@ -148,6 +148,23 @@ ColsTwiddle cols_twiddle(int N2, int RA, int RB) {
   return ct;
 }
 
+static std::map<int, float2 *> g_c2tw;
+const float2 *chan2_twiddle(int ND) {
+  std::lock_guard<std::mutex> lk(g_mutex);
+  auto it = g_c2tw.find(ND);
+  if (it != g_c2tw.end()) return it->second;
+  int const RB = ND / 32;
+  std::vector<float2> h((size_t)32 * RB);
+  for (int c = 0; c < 32; c++)
+    for (int l = 0; l < RB; l++) {
+      double const a = 2.0 * M_PI * (double)(l * c) / (double)ND;
+      h[(size_t)c * RB + l] = make_float2((float)cos(a), (float)sin(a));
+    }
+  float2 *d = upload_table(h);
+  if (d) g_c2tw[ND] = d;
+  return d;
+}
+
 static bool is_pow2(unsigned v) { return v && !(v & (v - 1)); }
 
 AnyPlan make_any_plan(int n) {

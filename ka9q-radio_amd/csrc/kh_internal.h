@@ -34,6 +34,8 @@ struct ColsTwiddle {
   const float2 *uj, *tq;
 };
 ColsTwiddle cols_twiddle(int N2, int RA, int RB);
+// kh_chan2's stage-A twiddles exp(+2 pi i l c / ND), laid out [c][l], c < 32, l < ND/32
+const float2 *chan2_twiddle(int ND);
 
 // ---------------------------------------------------------------- transforms of any 2,3,5,7-smooth size (kh_anyfft.cuh)
 struct AnyPlan {
@@ -180,6 +182,11 @@ int launch_filter_output(hipStream_t st, const float2 *spec, size_t spec_in_stri
                          int nblocks, int nchan, FmFront const &fm, int complex_out, const N0Pass1Args *n0 = nullptr,
                          int *n0_taken = nullptr);
 int chan_wave_supported(int ND, int olen);
+// the 32-points-per-lane form (kh_chan2_kernels.hip): baseband of every channel; stat (may be null): FM channels' block
+// statistics with fm_snr's ARGUMENT in .snr (launch_fm2 turns it into the SNR)
+int launch_chan2(hipStream_t st, const float2 *spec, size_t spec_in_stride, int N, const ChanDesc *chans,
+                 const float2 *response, int ND, int olen, float2 *out, size_t out_stride, int nblocks, int nchan,
+                 FmBlockStat *stat, int stat_stride, const N0Pass1Args *n0);
 int launch_chan_wave(hipStream_t st, const float2 *spec, size_t spec_in_stride, int N, const ChanDesc *chans,
                      const float2 *response, int ND, int olen, float2 *out, size_t out_stride, int nblocks, int nchan,
                      FmFront const &fm, const N0Pass1Args *n0);
@@ -216,6 +223,13 @@ int launch_demod(hipStream_t st, float2 *baseband, size_t bb_stride, int olen, i
 // (lin_list: the channels without PLL first; n_lin_nopll of them)
 // n0final (may be null): kh_n0_final's work rides in the FM finish launch; only valid if fm_finish_wave_usable() and n_fm > 0
 int fm_finish_wave_usable(int olen, int nblocks);
+// round 3's FM path behind launch_chan2 (kh_fm2_kernels.hip): kh_fm_snr_lanes + kh_fm_demod2.  stat: what launch_chan2
+// left, [channel][status_stride]; n0final (may be null) rides in the first of the two launches
+int fm2_usable(int ND, int olen, int nblocks);
+int launch_fm2(hipStream_t st, const float2 *baseband, size_t bb_stride, int olen, int nblocks, const DemodDesc *desc,
+               DemodState *state, float *audio, int16_t *pcm, size_t pcm_stride, int pcm_big_endian, void *status,
+               int status_stride, const int *fm_list, int n_fm, FmBlockStat *stat, const double *decay_pow, int parity,
+               const N0FinalArgs *n0final);
 
 // audio.c:32-135: one kh_rtp_chunk per PCM chunk of <= 480 words (plan: [nchan][plan_stride]), kh_rtp_state per channel
 int launch_rtp_plan(hipStream_t st, const int16_t *pcm, size_t pcm_stride, int olen, int nblocks, int nchan,

@@ -89,4 +89,64 @@ __device__ __forceinline__ void n0_pass1_body(N0Pass1Args const &Z, int wg, floa
   }
 }
 
+// one workgroup per input, one wave per block (16 waves: 16 blocks at a time; every lane issues all of its loads
+// before the first shuffle, so a block costs one memory round trip), then lane 0 applies radio.c:197-202 block by
+// block from LDS
+constexpr int N0_FT = 1024;
+// one workgroup (any multiple of 64 threads) per input i; sv/se hold N0_MAXB floats each.  Every wave takes blocks
+// wave, wave + nwaves, ...; the loads of four blocks are issued before the first shuffle.
+__device__ __forceinline__ void n0_final_body(N0FinalArgs const &Z, int i, float *sv, float *se) {
+  int const lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
+  int const nblocks = Z.nblocks;
+  const float *part1 = Z.part + (size_t)Z.ninputs * nblocks * N0_SLOTS;
+  constexpr int U = 4;
+  for (int b0 = wave; b0 < nblocks; b0 += U * nwaves) {
+    float es[U], s1[U], c1[U];
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+      int const b = b0 + u * nwaves;
+      es[u] = s1[u] = c1[u] = 0.f;
+      if (b < nblocks) {
+        size_t const pt = (size_t)i * nblocks + b;
+        const float *e = Z.energy_part + pt * Z.echunks;
+        for (int k = lane; k < Z.echunks; k += 64) es[u] += e[k];
+        if (Z.have_n0 && Z.valid) {
+          float2 const sc = reinterpret_cast<const float2 *>(part1 + pt * (2 * N0_GX))[lane]; // N0_GX == 64: one per lane
+          s1[u] = sc.x;
+          c1[u] = sc.y;
+        }
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+      int const b = b0 + u * nwaves;
+      float const e = n0_wave_sum(es[u]), s = n0_wave_sum(s1[u]), c = n0_wave_sum(c1[u]);
+      float v = NAN;
+      if (Z.have_n0) v = Z.valid ? (s / c) / ((float)Z.N * Z.samprate) : 0.f; // radio.c:433-435 ("Can this happen?"), 461, 464
+      if (lane == 0 && b < nblocks) {
+        se[b] = e / Z.L; // radio.c:197
+        sv[b] = v;
+      }
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x == 0 && Z.have_n0) {
+    float n0 = Z.n0_state[i];
+    for (int b = 0; b < nblocks; b++) {
+      float const v = sv[b];
+      if (!isnan(n0))
+        n0 = (float)((double)n0 + .005 * (double)(v - n0));
+      else
+        n0 = v;
+      sv[b] = n0;
+    }
+    Z.n0_state[i] = n0;
+  }
+  __syncthreads();
+  for (int b = threadIdx.x; b < nblocks; b += blockDim.x) {
+    Z.status[(size_t)i * nblocks + b].if_power = se[b];
+    Z.status[(size_t)i * nblocks + b].n0 = sv[b];
+  }
+}
+
 } // namespace kh
