@@ -814,7 +814,7 @@ static int enqueue_back(kh_bank *b, hipStream_t st, unsigned int nblocks, bool p
   bool const back2 = fm2_usable(b->ND, b->olen, (int)nblocks) != 0;
   if (back2) {
     if (launch_chan2(st, b->d_spec[sp], b->spec_stride, N, b->d_chans, b->d_resp, b->ND, b->olen, b->d_bb, b->bb_stride, nblocks, C,
-                     b->n_fm ? b->d_fmstat : nullptr, b->T, ride ? &z : nullptr))
+                     b->n_fm ? b->d_fmstat : nullptr, b->T, b->keep_baseband, ride ? &z : nullptr))
       return -1;
     taken = ride;
   } else if (launch_filter_output(st, b->d_spec[sp], b->spec_stride, N, 0, b->d_chans, b->d_resp, b->ND, b->olen, b->d_bb,

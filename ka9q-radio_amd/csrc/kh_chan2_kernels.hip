@@ -41,6 +41,7 @@ struct Chan2Args {
   FmBlockStat *stat;  // FM channels: bb_power, variance and (in .snr) the ratio fm_snr is fed, avg^2 / variance; may be null
   int stat_stride;
   int nchan, nblocks, npairs;
+  int store_all;      // 0: FM channels' blocks whose squelch is certainly closed are not stored
   unsigned magic;     // ceil(2^32 / nblocks): pair -> channel without a division
 };
 
@@ -66,10 +67,41 @@ struct C2Shape {
 };
 constexpr int C2_WAVE_LDS = 1152;
 
+// ---- filter.c:274-289: f[p] = response[p] * fdomain[m], p = (ND/2+1+i) mod ND, m = (N-ND/2+1+rotate+i) mod N.
+// Lane l holds p = RB a + l, a < 32.  i = p - H mod ND is linear in l except where it wraps: i = RB a + l + ND - H
+// for a < 16, RB a + l - H for a > 16, (l - 1) mod ND for a = 16; and m wraps at N only for channels at the band's
+// edge.  When no pair of the wavefront wraps (FAST), the 31 regular loads are one base address and immediate offsets.
+// rp: response + l, in global memory or in LDS (the two calls are separate so that each keeps its address space).
+template <int RB, bool FAST>
+__device__ __forceinline__ void c2_products(float2 (&v)[C2_RA], const float2 *__restrict__ rp, const float2 *__restrict__ fd, int m0,
+                                            int l, int N) {
+  constexpr int ND = C2_RA * RB, H = ND / 2 + 1;
+  if constexpr (FAST) {
+    const float2 *fl = fd + m0 + l;
+#pragma unroll
+    for (int a = 0; a < C2_RA; a++) {
+      if (a == 16) {
+        v[a] = cmul(rp[RB * a], fd[m0 + ((l - 1) & (ND - 1))]);
+      } else {
+        int const off = RB * a + (a < 16 ? ND - H : -H); // >= 0
+        v[a] = cmul(rp[RB * a], fl[off]);
+      }
+    }
+  } else {
+#pragma unroll
+    for (int a = 0; a < C2_RA; a++) {
+      int const i = (RB * a + l - H) & (ND - 1);
+      int m = m0 + i;
+      if (m >= N) m -= N;
+      v[a] = cmul(rp[RB * a], fd[m]);
+    }
+  }
+}
+
 // pairs are numbered block-fastest: pair q = ch * nblocks + b.  A wavefront's pairs are then blocks b .. b+3 of one
 // channel (one response fetch serves them) when a launch has several blocks, and neighbouring channels when it has one.
 template <int RB>
-__device__ __forceinline__ void chan2_wave(Chan2Args const &A, float2 *exw, int w, int lane64) {
+__device__ __forceinline__ void chan2_wave(Chan2Args const &A, float2 *exw, const float2 *twl, int w, int lane64) {
   using S = C2Shape<RB>;
   constexpr int RA = C2_RA, ND = S::ND, OLEN = S::OLEN, PITCH = S::PITCH, H = S::H;
   static_assert(RB == 32 || RB == 16, "N_dec = 1024 or 512");
@@ -82,35 +114,33 @@ __device__ __forceinline__ void chan2_wave(Chan2Args const &A, float2 *exw, int 
   ChanDesc const cd = A.chans[ch];
   int const N = A.N;
   const float2 *fd = A.spec + (size_t)cd.input * A.spec_in_stride + (size_t)b * N;
-  const float2 *rp = A.response + (size_t)ch * ND + l;
-
-  // ---- filter.c:274-289: f[p] = response[p] * fdomain[m], p = (ND/2+1+i) mod ND, m = (N-ND/2+1+rotate+i) mod N.
-  // Lane l holds p = RB a + l, a < 32.  i = p - H mod ND is linear in l except where it wraps: i = RB a + l + ND - H
-  // for a < 16, RB a + l - H for a > 16, (l - 1) mod ND for a = 16; and m wraps at N only for channels at the band's
-  // edge.  When no pair of the wavefront wraps, the 31 regular loads are one base address and immediate offsets.
+  // The response: each lane needs response[RB a + l], a < 32 -- the same 32 values in every group of the wavefront when its
+  // pairs are blocks of one channel (block-fastest numbering).  Fetching them per lane costs the texture path a 128-byte
+  // access per group and a; instead the wavefront loads the N_dec values once, 512 contiguous bytes an instruction,
+  // parks them in its exchange region and every lane picks its 32 from LDS (profiles/r03_s2_c4all_mem.txt: 1680 L1
+  // accesses per wavefront before this, more cycles on the CU's one texture unit than the kernel's VALU work on its four SIMDs).
+  bool const one_channel = __builtin_amdgcn_ballot_w64(ch != __builtin_amdgcn_readfirstlane(ch)) == 0;
   int m0 = N - ND / 2 + 1 + cd.rotate;
   if (m0 >= N) m0 -= N;
   if (m0 < 0) m0 += N;
+  bool const fast = __builtin_amdgcn_ballot_w64(m0 + ND > N) == 0;
   float2 v[RA];
-  if (__builtin_amdgcn_ballot_w64(m0 + ND > N) == 0) {
-    const float2 *fl = fd + m0 + l;
+  if (one_channel) {
+    const float2 *rc = A.response + (size_t)ch * ND + lane64;
 #pragma unroll
-    for (int a = 0; a < RA; a++) {
-      if (a == 16) {
-        v[a] = cmul(rp[RB * a], fd[m0 + ((l - 1) & (ND - 1))]);
-      } else {
-        int const off = RB * a + (a < 16 ? ND - H : -H); // >= 0
-        v[a] = cmul(rp[RB * a], fl[off]);
-      }
-    }
+    for (int k = 0; k < ND / 64; k++) exw[lane64 + 64 * k] = rc[64 * k];
+    c2_wave_sync();
+    if (fast)
+      c2_products<RB, true>(v, exw + l, fd, m0, l, N);
+    else
+      c2_products<RB, false>(v, exw + l, fd, m0, l, N);
+    c2_wave_sync(); // (the exchange below reuses the region)
   } else {
-#pragma unroll
-    for (int a = 0; a < RA; a++) {
-      int const i = (RB * a + l - H) & (ND - 1);
-      int m = m0 + i;
-      if (m >= N) m -= N;
-      v[a] = cmul(rp[RB * a], fd[m]);
-    }
+    const float2 *rp = A.response + (size_t)ch * ND + l;
+    if (fast)
+      c2_products<RB, true>(v, rp, fd, m0, l, N);
+    else
+      c2_products<RB, false>(v, rp, fd, m0, l, N);
   }
   if (__builtin_amdgcn_ballot_w64(cd.out_type == C2_CROSS_CONJ) != 0) { // filter.c:371-381, on the fly: the mirrored bin as well
     if (cd.out_type == C2_CROSS_CONJ) {
@@ -132,7 +162,7 @@ __device__ __forceinline__ void chan2_wave(Chan2Args const &A, float2 *exw, int 
   // ---- stage A
   reg_fft<RA, +1>(v);
   {
-    const float2 *tw = A.tw + l;
+    const float2 *tw = twl + l;
 #pragma unroll
     for (int c = 1; c < RA; c++) v[c] = cmul(v[c], tw[c * RB]);
   }
@@ -190,33 +220,42 @@ __device__ __forceinline__ void chan2_wave(Chan2Args const &A, float2 *exw, int 
     }
   }
 
-  if (valid) {
+  bool const fm_wave = A.stat != nullptr && __builtin_amdgcn_ballot_w64(cd.fm_stats != 0) != 0;
+  bool store = valid;
+  if (fm_wave) {
+    // ---- fm.c:53-68: baseband power, amplitude mean and variance; fm_snr's argument (kh_fm_demod2 takes it from there)
+    float amp[16];
+    float bb = 0.f, sa = 0.f;
+#pragma unroll
+    for (int m = 0; m < 16; m++) {
+      float const t = y[m].x * y[m].x + y[m].y * y[m].y;
+      bb += t;
+      amp[m] = __builtin_amdgcn_sqrtf(t);
+      sa += amp[m];
+    }
+    bb = c2_group_sum<RB>(bb);
+    sa = c2_group_sum<RB>(sa);
+    float const avg = sa / OLEN;
+    float var = 0.f;
+#pragma unroll
+    for (int m = 0; m < 16; m++) var += (amp[m] - avg) * (amp[m] - avg);
+    var = c2_group_sum<RB>(var) / (OLEN - 1);
+    float const r = avg * avg / var;
+    if (valid && cd.fm_stats && l == 0)
+      A.stat[(size_t)ch * A.stat_stride + b] = FmBlockStat{bb / OLEN, var, r, 0.f, make_float2(0.f, 0.f), make_float2(0.f, 0.f)};
+    // A block whose squelch is closed is never read (kh_fm_demod2), and a block is open only if its SNR or the block
+    // before's exceeds 4 (fm.c:73-78), i.e. fm_snr's argument exceeds ~6.1 (fm_snr is increasing; fm_snr(5) = 2.5).  When
+    // the caller does not want the FM channels' baseband, blocks that are certainly closed skip the store; the block
+    // before is known here when it sits in the neighbouring group of this wavefront.
+    float const r_prev = __shfl(r, (lane64 & ~(RB - 1)) - RB, 64);
+    bool const prev_known = g > 0 && b > 0;
+    if (cd.fm_stats && !A.store_all && prev_known && r <= 5.f && r_prev <= 5.f) store = false;
+  }
+  if (store) {
     float2 *o = A.out + (size_t)ch * A.out_stride + (size_t)b * OLEN + l;
 #pragma unroll
     for (int m = 0; m < 16; m++) o[RB * m] = y[m];
   }
-  if (A.stat == nullptr || __builtin_amdgcn_ballot_w64(cd.fm_stats != 0) == 0) return;
-
-  // ---- fm.c:53-68: baseband power, amplitude mean and variance; fm_snr's argument (kh_fm_snr_lanes takes it from there)
-  float amp[16];
-  float bb = 0.f, sa = 0.f;
-#pragma unroll
-  for (int m = 0; m < 16; m++) {
-    float const t = y[m].x * y[m].x + y[m].y * y[m].y;
-    bb += t;
-    amp[m] = __builtin_amdgcn_sqrtf(t);
-    sa += amp[m];
-  }
-  bb = c2_group_sum<RB>(bb);
-  sa = c2_group_sum<RB>(sa);
-  float const avg = sa / OLEN;
-  float var = 0.f;
-#pragma unroll
-  for (int m = 0; m < 16; m++) var += (amp[m] - avg) * (amp[m] - avg);
-  var = c2_group_sum<RB>(var) / (OLEN - 1);
-  if (valid && cd.fm_stats && l == 0)
-    A.stat[(size_t)ch * A.stat_stride + b] =
-        FmBlockStat{bb / OLEN, var, avg * avg / var, 0.f, make_float2(0.f, 0.f), make_float2(0.f, 0.f)};
 }
 
 template <int RB>
@@ -225,13 +264,21 @@ __host__ __device__ constexpr int chan2_waves(int npairs) { return (npairs + C2S
 // Workgroups [0, nchan_wg) carry C2_WAVES channel wavefronts each; the rest are compute_n0's second iteration
 // (radio.c:451-462, kh_n0.cuh) over N0_GX slices per (input, block), as in kh_back_a.
 constexpr int C2_WAVES = 2;
-template <int RB>
-__global__ __launch_bounds__(64 * C2_WAVES) void kh_chan2(Chan2Args A, N0Pass1Args Z, int nchan_wg, int nwaves) {
+template <int RB, int OCC>
+__global__ __launch_bounds__(64 * C2_WAVES, OCC) void kh_chan2(Chan2Args A, N0Pass1Args Z, int nchan_wg, int nwaves) {
   __shared__ __attribute__((aligned(16))) float2 ex[C2_WAVES * C2_WAVE_LDS];
+  __shared__ float2 twl[C2_RA * RB]; // stage A's twiddles, [c][l]: one coalesced copy per workgroup instead of 31 loads per lane
   if ((int)blockIdx.x < nchan_wg) {
+    for (int k = threadIdx.x; k < C2_RA * RB; k += 64 * C2_WAVES) twl[k] = A.tw[k];
+    __syncthreads();
+    // workgroups are dealt round-robin over the 8 XCDs (b and b + 8 share one), each with an L2 of its own: XCD x takes a
+    // contiguous eighth of the pairs, so that the bins neighbouring channels share (a 12.5 kHz raster reads every bin
+    // 2.5 times) are fetched into ONE L2 once instead of into several from HBM (speed only; any placement is correct)
+    int const per = nchan_wg >> 3; // nchan_wg is a multiple of 8
+    int const wg = ((int)blockIdx.x & 7) * per + ((int)blockIdx.x >> 3);
     int const wave = threadIdx.x >> 6;
-    int const w = blockIdx.x * C2_WAVES + wave;
-    if (w < nwaves) chan2_wave<RB>(A, ex + wave * C2_WAVE_LDS, w, threadIdx.x & 63);
+    int const w = wg * C2_WAVES + wave;
+    if (w < nwaves) chan2_wave<RB>(A, ex + wave * C2_WAVE_LDS, twl, w, threadIdx.x & 63);
   } else {
     n0_pass1_body(Z, blockIdx.x - nchan_wg, reinterpret_cast<float *>(ex));
   }
@@ -240,15 +287,19 @@ __global__ __launch_bounds__(64 * C2_WAVES) void kh_chan2(Chan2Args A, N0Pass1Ar
 template <int RB>
 static void launch_chan2_rb(hipStream_t st, Chan2Args const &A, const N0Pass1Args *n0) {
   int const nwaves = chan2_waves<RB>(A.npairs);
-  int const nchan_wg = (nwaves + C2_WAVES - 1) / C2_WAVES;
+  int const nchan_wg = (((nwaves + C2_WAVES - 1) / C2_WAVES) + 7) & ~7;
   N0Pass1Args const Z = n0 ? *n0 : N0Pass1Args{};
   int const extra = n0 ? n0->gx * n0->nblocks * n0->ninputs : 0;
-  hipLaunchKernelGGL(kh_chan2<RB>, dim3(nchan_wg + extra), dim3(64 * C2_WAVES), 0, st, A, Z, nchan_wg, nwaves);
+  static int const occ = getenv("KA9Q_HIP_C2_OCC") ? atoi(getenv("KA9Q_HIP_C2_OCC")) : 1; // experiment: forced waves per SIMD
+  if (occ == 4)
+    hipLaunchKernelGGL((kh_chan2<RB, 4>), dim3(nchan_wg + extra), dim3(64 * C2_WAVES), 0, st, A, Z, nchan_wg, nwaves);
+  else
+    hipLaunchKernelGGL((kh_chan2<RB, 1>), dim3(nchan_wg + extra), dim3(64 * C2_WAVES), 0, st, A, Z, nchan_wg, nwaves);
 }
 
 int launch_chan2(hipStream_t st, const float2 *spec, size_t spec_in_stride, int N, const ChanDesc *chans,
                  const float2 *response, int ND, int olen, float2 *out, size_t out_stride, int nblocks, int nchan,
-                 FmBlockStat *stat, int stat_stride, const N0Pass1Args *n0) {
+                 FmBlockStat *stat, int stat_stride, int store_all, const N0Pass1Args *n0) {
   if (!chan_wave_supported(ND, olen)) {
     set_error("filter output (32 points per lane): N_dec %d / olen %d unsupported", ND, olen);
     return -1;
@@ -262,7 +313,7 @@ int launch_chan2(hipStream_t st, const float2 *spec, size_t spec_in_stride, int 
   if (!tw) return -1;
   unsigned const magic = (unsigned)(((1ull << 32) + (unsigned)nblocks - 1) / (unsigned)nblocks);
   Chan2Args const A{spec, spec_in_stride, N, chans, response, out, out_stride, tw, stat, stat_stride, nchan, nblocks,
-                    nchan * nblocks, nblocks == 1 ? 0u : magic};
+                    nchan * nblocks, store_all, nblocks == 1 ? 0u : magic};
   if (ND == 1024)
     launch_chan2_rb<32>(st, A, n0);
   else

@@ -931,7 +931,7 @@ int launch_filter_output(hipStream_t st, const float2 *spec, size_t spec_in_stri
     if (n0_taken) *n0_taken = n0 != nullptr;
     if (fm.stat == nullptr && fm2_usable(ND, olen, nblocks)) // no FM epilogue wanted: the 32-points-per-lane form
       return launch_chan2(st, spec, spec_in_stride, N, chans, response, ND, olen, static_cast<float2 *>(out), out_stride, nblocks,
-                          nchan, nullptr, 0, n0);
+                          nchan, nullptr, 0, 1, n0);
     return launch_chan_wave(st, spec, spec_in_stride, N, chans, response, ND, olen, static_cast<float2 *>(out), out_stride,
                             nblocks, nchan, fm, n0);
   }

@@ -27,61 +27,59 @@
 
 namespace kh {
 
-// fm_snr (fm.c:190-205) with a different argument in every lane: kh_fm.cuh's fm_snr() without the scalar registers.
-// Same polynomial pieces, same iteration and stopping rule, hence the same value for the same r.
-static __device__ double fm_snr_lane(double r) {
+// fm_snr (fm.c:190-205) with a different argument in every lane.  Same polynomial pieces as kh_fm.cuh's fm_snr(), same
+// iteration, same stopping rule, hence the same value for the same r; the pieces' coefficients come from LDS (`coef`:
+// KH_XI_SEGS x 12 doubles, copied there by the caller), and the loop is cut in two so that the round itself -- 20 fp64
+// operations on one lane's chain, ~50 rounds for the slowest lane of a wavefront of noise blocks -- carries one exit test:
+// a lone wavefront pays ~10 cycles per instruction, scalar bookkeeping included (profiles/r03_s1_c4all_sq.txt: 1250
+// vector + 1570 scalar instructions per wavefront in 12.5 us before this).
+static __device__ double fm_snr_lane(double r, const double *coef) {
   double thetasq = r;
-  double othetasq = r + 10;
   if (r <= M_PI / (4 - M_PI)) return 0;
   if (r > 100) return r;
   double const r1 = 1 + r;
-  double lo = 1.0, hi = 0.0, mid = 0.0, scale = 0.0, c[KH_XI_DEG + 1]; // empty segment: the first round loads one
-#pragma unroll
-  for (int k = 0; k <= KH_XI_DEG; k++) c[k] = 0.0;
   int guard = 0; // the reference loop has no bound; NaN input falls through both tests above and exits here
-  while (fabs(thetasq - othetasq) > .001 && guard++ < 10000) {
-    othetasq = thetasq;
-    if (!(thetasq >= 0.0 && thetasq <= 100.0)) {
+  bool done = false;
+  while (!done) {
+    if (!(thetasq >= 0.0 && thetasq <= 100.0)) { // (not reached from fm_snr's own range checks: the series itself)
+      double const o = thetasq;
       thetasq = fm_xi(thetasq) * r1 - 2;
+      done = !(fabs(thetasq - o) > .001) || ++guard >= 10000;
       continue;
     }
-    if (!(thetasq >= lo && thetasq < hi)) {
-      int g = (int)(thetasq * (1.0 / KH_XI_GRID));
-      g = g < KH_XI_NLUT ? g : KH_XI_NLUT - 1;
-      int const seg = kh_xi_lut[g];
-      double const e1 = kh_xi_edges[seg + 1];
-      lo = kh_xi_edges[seg];
-      hi = seg == KH_XI_SEGS - 1 ? 101.0 : e1; // thetasq == 100 belongs to the last segment
-      mid = 0.5 * (lo + e1);
-      scale = 2.0 / (e1 - lo);
+    constexpr double E[KH_XI_SEGS + 1] = KH_XI_EDGES;
+    int seg = 0;
 #pragma unroll
-      for (int k = 0; k <= KH_XI_DEG; k++) c[k] = kh_xi_coeffs[seg][k];
+    for (int k = 1; k < KH_XI_SEGS; k++) seg += thetasq >= E[k] ? 1 : 0;
+    double lo = E[0], e1 = E[1];
+#pragma unroll
+    for (int k = 1; k < KH_XI_SEGS; k++)
+      if (seg == k) lo = E[k], e1 = E[k + 1];
+    double const hi = seg == KH_XI_SEGS - 1 ? 101.0 : e1; // thetasq == 100 belongs to the last segment
+    double const mid = 0.5 * (lo + e1), scale = 2.0 / (e1 - lo);
+    double c[KH_XI_DEG + 1];
+    const double2 *cs = reinterpret_cast<const double2 *>(coef + seg * (KH_XI_DEG + 1));
+#pragma unroll
+    for (int k = 0; k <= KH_XI_DEG; k += 2) {
+      double2 const t = cs[k / 2];
+      c[k] = t.x;
+      c[k + 1] = t.y;
     }
-    double const u = (thetasq - mid) * scale;
-    double const u2 = u * u, u4 = u2 * u2, u8 = u4 * u4;
-    double const p01 = fma(c[1], u, c[0]), p23 = fma(c[3], u, c[2]), p45 = fma(c[5], u, c[4]);
-    double const p67 = fma(c[7], u, c[6]), p89 = fma(c[9], u, c[8]), pab = fma(c[11], u, c[10]);
-    double const q0 = fma(p23, u2, p01), q1 = fma(p67, u2, p45), q2 = fma(pab, u2, p89);
-    double const xi = fma(q2, u8, fma(q1, u4, q0));
-    thetasq = xi * r1 - 2;
+    bool inside;
+    do {
+      double const o = thetasq;
+      double const u = (thetasq - mid) * scale;
+      double const u2 = u * u, u4 = u2 * u2, u8 = u4 * u4;
+      double const p01 = fma(c[1], u, c[0]), p23 = fma(c[3], u, c[2]), p45 = fma(c[5], u, c[4]);
+      double const p67 = fma(c[7], u, c[6]), p89 = fma(c[9], u, c[8]), pab = fma(c[11], u, c[10]);
+      double const q0 = fma(p23, u2, p01), q1 = fma(p67, u2, p45), q2 = fma(pab, u2, p89);
+      double const xi = fma(q2, u8, fma(q1, u4, q0));
+      thetasq = xi * r1 - 2;
+      done = !(fabs(thetasq - o) > .001) || ++guard >= 10000;
+      inside = thetasq >= lo && thetasq < hi;
+    } while (!done && inside);
   }
   return thetasq;
-}
-
-// stat[ch][b].snr holds avg^2 / variance on entry (kh_chan2) and fmaxf(0, fm_snr(.)) on return (fm.c:69-70).
-// Workgroups beyond nsnr_wg (if any) are kh_n0_final's work, one per input.
-__global__ __launch_bounds__(256) void kh_fm_snr_lanes(FmBlockStat *__restrict__ stat, int stat_stride, const int *__restrict__ list,
-                                                       int n_fm, int nblocks, unsigned magic, int nsnr_wg, N0FinalArgs Z) {
-  __shared__ float sv[N0_MAXB], se[N0_MAXB];
-  if ((int)blockIdx.x >= nsnr_wg) {
-    n0_final_body(Z, blockIdx.x - nsnr_wg, sv, se);
-    return;
-  }
-  int const q = blockIdx.x * 256 + threadIdx.x;
-  if (q >= n_fm * nblocks) return;
-  int const ci = magic ? (int)__umulhi((unsigned)q, magic) : q, b = q - ci * nblocks;
-  FmBlockStat *s = stat + (size_t)list[ci] * stat_stride + b;
-  s->snr = fmaxf(0.0f, (float)fm_snr_lane((double)s->snr));
 }
 
 struct Fm2Args {
@@ -111,12 +109,19 @@ __device__ __forceinline__ float fm2_group_sum(float v) {
 }
 
 constexpr int FM2_MAXBP = 16; // blocks per pass: at most 16 wavefronts per workgroup
+constexpr int FM2_MAXT = 64;  // blocks per launch: their SNRs are one wavefront's lanes
 // one workgroup per FM channel; blockDim.x / G groups of G lanes, group `bl` of a pass takes block b0 + bl
 template <int G>
-__global__ __launch_bounds__(1024) void kh_fm_demod2(Fm2Args F) {
+__global__ __launch_bounds__(1024) void kh_fm_demod2(Fm2Args F, int nfm_wg, N0FinalArgs Z) {
   constexpr int K = 8, OLEN = K * G, PPW = 64 / G;
   static_assert(G == 32 || G == 64, "olen = 256 or 512");
   __shared__ double shB[2][FM2_MAXBP];
+  __shared__ __attribute__((aligned(16))) double sh_coef[KH_XI_SEGS * (KH_XI_DEG + 1)];
+  __shared__ float sh_snr[FM2_MAXT], sh_se[FM2_MAXT];
+  if ((int)blockIdx.x >= nfm_wg) { // kh_n0_final's work (one workgroup per input) rides in this launch
+    n0_final_body(Z, blockIdx.x - nfm_wg, sh_snr, sh_se);
+    return;
+  }
   int const lane64 = threadIdx.x & 63, wave = threadIdx.x >> 6;
   int const l = lane64 % G, bl = wave * PPW + lane64 / G;
   int const BP = (blockDim.x >> 6) * PPW;
@@ -133,6 +138,17 @@ __global__ __launch_bounds__(1024) void kh_fm_demod2(Fm2Args F) {
   double const Ablk = F.decay_pow[OLEN];
   double const dpl = F.decay_pow[K * l]; // decay^(K l)
   const float2 *bbc = F.bb + (size_t)ch * F.bb_stride;
+  // ---- fm.c:69-70: the Rice-corrected SNR of every block of the launch, a lane each (wavefront 0; the others wait)
+  if (wave == 0) {
+    float const r = lane64 < nblocks ? fs[lane64].snr : 0.f; // kh_chan2 left avg^2 / variance there
+    for (int k = lane64; k < KH_XI_SEGS * (KH_XI_DEG + 1); k += 64) sh_coef[k] = (&kh_xi_coeffs[0][0])[k];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    float const snr = fmaxf(0.0f, (float)fm_snr_lane((double)r, sh_coef));
+    if (lane64 < nblocks) sh_snr[lane64] = snr;
+  }
+  __syncthreads();
   double c_pass = (double)lastaudio_in; // lastaudio on entry to the pass's first block
   int pp = 0;
   for (int b0 = 0; b0 < nblocks; b0 += BP, pp ^= 1) {
@@ -140,9 +156,9 @@ __global__ __launch_bounds__(1024) void kh_fm_demod2(Fm2Args F) {
     bool const have = b < nblocks;
     // ---- fm.c:73-78 in closed form (fm_counter_after, kh_demod_kernels.hip): the counter after block j is 1 if snr_j > 4,
     // else max(so_in - 1, 0) for j = 0 and 0 for j >= 1; a block demodulates iff snr > 4 or the counter before it is positive
-    float const snr_b = have ? fs[b].snr : 0.f;
-    float const snr_p = (have && b >= 1) ? fs[b - 1].snr : 0.f;
-    float const snr_pp = (have && b >= 2) ? fs[b - 2].snr : 0.f;
+    float const snr_b = have ? sh_snr[b] : 0.f;
+    float const snr_p = (have && b >= 1) ? sh_snr[b - 1] : 0.f;
+    float const snr_pp = (have && b >= 2) ? sh_snr[b - 2] : 0.f;
     int const dec_in = so_in - 1 > 0 ? so_in - 1 : 0;
     int const cnt_pp = b >= 2 ? (snr_pp > 4.f ? 1 : (b == 2 ? dec_in : 0)) : so_in; // counter before block b - 1
     int const cnt_p = b >= 1 ? (snr_p > 4.f ? 1 : (b == 1 ? dec_in : 0)) : so_in;  // counter before block b
@@ -369,37 +385,37 @@ __global__ __launch_bounds__(1024) void kh_fm_demod2(Fm2Args F) {
 
 int fm2_usable(int ND, int olen, int nblocks) {
   static int const env = getenv("KA9Q_HIP_BACK2") ? atoi(getenv("KA9Q_HIP_BACK2")) : 1; // A/B switch: 0 = round 2's kernels
-  return env && chan_wave_supported(ND, olen) && nblocks >= 1 && nblocks <= N0_MAXB;
+  return env && chan_wave_supported(ND, olen) && nblocks >= 1 && nblocks <= FM2_MAXT;
 }
 
-// n0final (may be null): kh_n0_final's work rides in the SNR launch
+// n0final (may be null): kh_n0_final's work rides in the launch
 int launch_fm2(hipStream_t st, const float2 *baseband, size_t bb_stride, int olen, int nblocks, const DemodDesc *desc,
                DemodState *state, float *audio, int16_t *pcm, size_t pcm_stride, int pcm_big_endian, void *status,
                int status_stride, const int *fm_list, int n_fm, FmBlockStat *stat, const double *decay_pow, int parity,
                const N0FinalArgs *n0final) {
-  if (nblocks <= 0) return 0;
-  if (olen != 256 && olen != 512) {
-    set_error("FM demodulator (workgroup per channel): olen %d unsupported", olen);
+  if (nblocks <= 0 || n_fm <= 0) return 0;
+  if ((olen != 256 && olen != 512) || nblocks > FM2_MAXT) {
+    set_error("FM demodulator (workgroup per channel): olen %d / %d blocks unsupported", olen, nblocks);
     return -1;
   }
-  int const npairs = n_fm * nblocks;
-  int const nsnr_wg = (npairs + 255) / 256;
   N0FinalArgs const Z = n0final ? *n0final : N0FinalArgs{};
-  unsigned const magic = nblocks == 1 ? 0u : (unsigned)(((1ull << 32) + (unsigned)nblocks - 1) / (unsigned)nblocks);
-  if (nsnr_wg + (n0final ? n0final->ninputs : 0) > 0)
-    hipLaunchKernelGGL(kh_fm_snr_lanes, dim3(nsnr_wg + (n0final ? n0final->ninputs : 0)), dim3(256), 0, st, stat, status_stride,
-                       fm_list, n_fm, nblocks, magic, nsnr_wg, Z);
-  if (n_fm > 0) {
-    Fm2Args const F{nblocks, desc, state, parity, stat, status_stride, baseband, bb_stride, decay_pow, audio, pcm, pcm_stride,
-                    pcm_big_endian, static_cast<kh_status *>(status), status_stride, fm_list};
-    int const G = olen / 8, ppw = 64 / G;
-    int nw = (nblocks + ppw - 1) / ppw;
-    if (nw > FM2_MAXBP / ppw) nw = FM2_MAXBP / ppw; // at most 16 blocks per pass
-    if (G == 32)
-      hipLaunchKernelGGL(kh_fm_demod2<32>, dim3(n_fm), dim3(64 * nw), 0, st, F);
-    else
-      hipLaunchKernelGGL(kh_fm_demod2<64>, dim3(n_fm), dim3(64 * nw), 0, st, F);
-  }
+  Fm2Args const F{nblocks, desc, state, parity, stat, status_stride, baseband, bb_stride, decay_pow, audio, pcm, pcm_stride,
+                  pcm_big_endian, static_cast<kh_status *>(status), status_stride, fm_list};
+  int const G = olen / 8, ppw = 64 / G;
+  // wavefronts per channel: enough of them chip-wide to hide each other's memory round trips (~8 per SIMD), but no more --
+  // every workgroup pays its own chain of dependent loads (list -> descriptor, state -> statistics) and the SNR iteration
+  // before its first block, so a large bank is better served by few wavefronts that walk a channel's blocks in passes
+  static int const nw_env = getenv("KA9Q_HIP_FM2_WAVES") ? atoi(getenv("KA9Q_HIP_FM2_WAVES")) : 0;
+  int nw = nw_env > 0 ? nw_env : (8192 + n_fm - 1) / n_fm;
+  int const nw_blocks = (nblocks + ppw - 1) / ppw;
+  if (nw > nw_blocks) nw = nw_blocks;
+  if (nw > FM2_MAXBP / ppw) nw = FM2_MAXBP / ppw; // at most 16 blocks per pass
+  if (nw < 1) nw = 1;
+  dim3 const grid(n_fm + (n0final ? n0final->ninputs : 0));
+  if (G == 32)
+    hipLaunchKernelGGL(kh_fm_demod2<32>, grid, dim3(64 * nw), 0, st, F, n_fm, Z);
+  else
+    hipLaunchKernelGGL(kh_fm_demod2<64>, grid, dim3(64 * nw), 0, st, F, n_fm, Z);
   return KH_HIP(hipGetLastError()) ? 0 : -1;
 }
 

@@ -186,7 +186,8 @@ int chan_wave_supported(int ND, int olen);
 // statistics with fm_snr's ARGUMENT in .snr (launch_fm2 turns it into the SNR)
 int launch_chan2(hipStream_t st, const float2 *spec, size_t spec_in_stride, int N, const ChanDesc *chans,
                  const float2 *response, int ND, int olen, float2 *out, size_t out_stride, int nblocks, int nchan,
-                 FmBlockStat *stat, int stat_stride, const N0Pass1Args *n0);
+                 FmBlockStat *stat, int stat_stride, int store_all, const N0Pass1Args *n0);
+// (store_all == 0: FM channels' blocks whose squelch is certainly closed are not written)
 int launch_chan_wave(hipStream_t st, const float2 *spec, size_t spec_in_stride, int N, const ChanDesc *chans,
                      const float2 *response, int ND, int olen, float2 *out, size_t out_stride, int nblocks, int nchan,
                      FmFront const &fm, const N0Pass1Args *n0);
