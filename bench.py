@@ -132,7 +132,7 @@ def time_steps(bank, step, steps, warm=5):
     return (time.perf_counter() - t0) / steps
 
 
-def measure_shape(pyka9q, torch, device, shape, plan, nblocks, label, steps=40):
+def measure_shape(pyka9q, torch, device, shape, plan, nblocks, label, steps=40, valu_key=None):
     """one of the other BASELINE configurations on this GPU: step time (as the headline: raw input resident, launches
     back to back), per-stage HIP-event times, SURVEY.md 8(d) bytes and what fraction of the HBM roofline they are"""
     P = shape.P
@@ -155,11 +155,16 @@ def measure_shape(pyka9q, torch, device, shape, plan, nblocks, label, steps=40):
         bank.execute(nblocks, sync=False)
 
     dt = time_steps(bank, step, steps)
-    bank.profile(1)
+    bank.profile(1)  # every stage alone on the chip
     for _ in range(5):
         step()
     bank.sync()
     st = bank.stage_times()
+    bank.profile(2)  # the two-stream pipeline, event pairs on the stream each stage runs on
+    for _ in range(12):
+        step()
+    bank.sync()
+    st2 = bank.stage_times()
     bank.profile(0)
     bank.close()
     del x
@@ -173,47 +178,117 @@ def measure_shape(pyka9q, torch, device, shape, plan, nblocks, label, steps=40):
             "realtime_factor": round((nblocks * shape.L / shape.fs) / dt, 1),
             "algorithmic_bytes_per_step": alg, "algorithmic_GBps": round(alg / dt / 1e9, 1),
             "frac_of_hbm_peak": round(alg / dt / 1e9 / HBM_PEAK_GBPS, 4),
-            "stage_us_hip_events": {k: round(1e3 * ms / n, 1) for k, (ms, n) in st.items() if n}}
+            "stage_us_hip_events": {k: round(1e3 * ms / n, 1) for k, (ms, n) in st.items() if n},
+            "stage_us_pipelined": {k: round(1e3 * ms / n, 1) for k, (ms, n) in st2.items() if n},
+            "back_half": back_half_ceilings(shape, plan, nblocks, st, st2, valu_key)}
+
+
+SIMDS, CLOCK_HZ = 1024, 2.4e9  # /opt/skills/guides/MI355X_MICROARCH.md: 256 CUs x 4 SIMDs, 2.4 GHz peak engine clock
+
+
+def back_half_ceilings(shape, plan, nblocks, st_alone, st_pipe, valu_key):
+    """the fused filter / demodulator kernels against BOTH of their ceilings: SURVEY.md 8(d)'s bytes per (channel, block)
+    (8 N_dec bins + 8 N_dec response + b_out olen) over their HIP-event durations as a fraction of the HBM peak, and --
+    they are bound by instruction issue, not by bytes -- the vector instructions one launch issues (SQ_INSTS_VALU from
+    the committed rocprofv3 --pmc pass of the same shape, profiles/r03_valu_counts.json) x 4 cycles / 1024 SIMDs / 2.4 GHz
+    against the same duration."""
+    alg = 0
+    for ch in plan:
+        alg += nblocks * (16 * shape.ND + (4 if ch.get("channels", 1) == 2 else 2) * shape.olen)
+    out = {"algorithmic_bytes_per_launch": alg}
+    for tag, st in (("alone", st_alone), ("pipelined", st_pipe)):
+        us = sum(1e3 * st[k][0] / st[k][1] for k in ("chan", "demod") if st.get(k, (0, 0))[1])
+        if us > 0:
+            out[f"us_{tag}"] = round(us, 1)
+            out[f"frac_of_hbm_peak_{tag}"] = round(alg / (us * 1e-6) / 1e9 / HBM_PEAK_GBPS, 4)
+    try:
+        counts = json.load(open(os.path.join(ROOT, "profiles", "r03_valu_counts.json")))[valu_key]
+        insts = sum(k["SQ_INSTS_VALU"] for k in counts["kernels"].values())
+        bound_us = insts * 4 / SIMDS / CLOCK_HZ * 1e6
+        out["roofline_valu"] = {"bound": "valu_issue", "SQ_INSTS_VALU_per_launch": int(insts), "kernels": sorted(counts["kernels"]),
+                                "issue_bound_us": round(bound_us, 1), "source": counts["source"],
+                                "frac_alone": round(bound_us / out["us_alone"], 4) if out.get("us_alone") else None,
+                                "frac_pipelined": round(bound_us / out["us_pipelined"], 4) if out.get("us_pipelined") else None}
+    except (OSError, ValueError, KeyError, TypeError):
+        pass
+    return out
 
 
 def shapes_leg(pyka9q, torch, device):
     out = []
     jobs = [
         (workloads.CONFIG4, workloads.shard_plan(workloads.config4_plan(), workloads.CONFIG4, 8, 3)[0], 16,
-         "config 4, one GPU's share of 8: 64 MS/s cf32, N = 2^20, D = 2048, 512 of 4096 NBFM channels (contiguous in frequency)"),
+         "config 4, one GPU's share of 8: 64 MS/s cf32, N = 2^20, D = 2048, 512 of 4096 NBFM channels (contiguous in frequency)", "c4share"),
         (workloads.CONFIG3, workloads.shard_plan(workloads.config3_plan(), workloads.CONFIG3, 4, 1)[0], 32,
-         "config 3, one GPU's share of 4: 20 MS/s cf32, N = 2^19, D = 512, 256 of 1024 channels (NBFM / envelope AM / USB with hang AGC)"),
+         "config 3, one GPU's share of 4: 20 MS/s cf32, N = 2^19, D = 512, 256 of 1024 channels (NBFM / envelope AM / USB with hang AGC)", "c3share"),
         (workloads.CONFIG5, workloads.config5_plan(), 32,
-         "config 5: 256 independent pipelines at 192 kS/s (N = 8192, D = 4), Doppler NCO -> LO2 NCO -> filter -> linear demodulator with PLL + AGC"),
+         "config 5: 256 independent pipelines at 192 kS/s (N = 8192, D = 4), Doppler NCO -> LO2 NCO -> filter -> linear demodulator with PLL + AGC", "c5"),
+        (workloads.CONFIG4, workloads.config4_plan(), 16,
+         "config 4 with all 4096 NBFM channels on ONE GPU: 64 MS/s cf32, N = 2^20, D = 2048 (north_star's channel count, an eighth of its GPUs)", "c4all"),
     ]
-    for shape, plan, nb, label in jobs:
+    for shape, plan, nb, label, key in jobs:
         try:
-            out.append(measure_shape(pyka9q, torch, device, shape, plan, nb, label, steps=10 if shape.P > 1 else 40))
+            out.append(measure_shape(pyka9q, torch, device, shape, plan, nb, label, steps=10 if shape.P > 1 else 40, valu_key=key))
         except Exception as e:  # an extra leg must never cost the bench line
             out.append({"workload": label, "error": repr(e)})
     return out
 
 
-def realtime_leg(pyka9q, torch, device, blocks=1000):
-    """BASELINE metric (i) on configs[1]'s stream: every 12.5 kHz channel the 8 MS/s band holds (640), block by block in
-    real time.  The producer writes s16le I/Q (IQ_PT, radio.c:159-167) into the library's pinned ring, kh_bank_stream_submit
-    moves it with hipMemcpyAsync on the copy stream and runs the launch behind it; the PCM of all channels is read back
-    after every block.  `late_blocks` counts blocks whose PCM was not back before the next block was due (a backlog)."""
-    shape = workloads.CONFIG2
-    plan = workloads.config2_plan(640)
+def paced_run(bank, shape, raw, nsrc, blocks, nchan):
+    """one block per submit, released at k * L / fs; the PCM of every channel is read back before the block counts as done"""
+    pcm = np.empty((nchan, shape.olen), np.int16)
+    period = shape.L / shape.fs
+    lat, late = [], 0
+    t0 = time.perf_counter() + 0.01
+    for k in range(blocks):
+        due = t0 + k * period
+        while True:
+            now = time.perf_counter()
+            if now >= due:
+                break
+            time.sleep(min(due - now, 0.002))
+        s = bank.stream_slot(0, np.int16, 2 * shape.L)
+        s[:] = raw[k % nsrc]
+        bank.stream_submit(1)
+        bank.pcm_all(1, pcm)
+        done = time.perf_counter()
+        lat.append(done - due)
+        if done > due + period:
+            late += 1
+    lat = np.array(lat)
+    return {"blocks": blocks, "blocks_per_submit": 1, "late_blocks": int(late), "holds_realtime": bool(late == 0),
+            "latency_ms_release_to_pcm": {"mean": round(1e3 * float(lat.mean()), 3), "p99": round(1e3 * float(np.percentile(lat, 99)), 3),
+                                          "max": round(1e3 * float(lat.max()), 3)},
+            "busy_fraction": round(float(lat.mean()) / period, 4),
+            "H2D_GBps_while_busy": round(4 * shape.L / float(lat.mean()) / 1e9, 2)}
+
+
+def realtime_leg(pyka9q, torch, device, shape=None, plan=None, label=None, blocks=1000, full=True):
+    """BASELINE metric (i): every channel of a configuration's band, block by block in real time.  The producer writes
+    s16le I/Q (IQ_PT, radio.c:159-167) into the library's pinned ring, kh_bank_stream_submit moves it with hipMemcpyAsync
+    on the copy stream and runs the launch behind it; the PCM of all channels is read back after every block.
+    `late_blocks` counts blocks whose PCM was not back before the next block was due (a backlog).  full: also the unpaced
+    PCIe-inclusive rate with the producer's own copy into the ring."""
+    shape = shape or workloads.CONFIG2
+    plan = plan if plan is not None else workloads.config2_plan(640)
     Tr = 4
-    nsrc = 16  # distinct blocks of input, cycled
+    nsrc = 16 if shape.L <= 131072 else 8  # distinct blocks of input, cycled
     x = make_wideband_torch(shape, plan, nsrc * shape.L, device)
     raw = torch.clamp(torch.round(x * (32767.0 * 4.0)), -32768, 32767).to(torch.int16).cpu().numpy().reshape(nsrc, 2 * shape.L)
     del x
     bank = build_bank(pyka9q, shape, plan, Tr, payload=pyka9q.KH_PT_IQ16LE)
     bank.stream_open(4)
-    res = {"workload": "configs[1] stream, s16le wire format (IQ_PT), all 640 raster channels, pinned host ring -> hipMemcpyAsync "
-                       "on a copy stream -> launch; PCM of every channel read back",
-           "channels": len(plan), "block_ms": round(1e3 * shape.L / shape.fs, 3)}
+    kinds = {}
+    for ch in plan:
+        kinds[ch["kind"]] = kinds.get(ch["kind"], 0) + 1
+    res = {"workload": label or "configs[1] stream, s16le wire format (IQ_PT), all 640 raster channels, pinned host ring -> hipMemcpyAsync "
+                                "on a copy stream -> launch; PCM of every channel read back",
+           "channels": len(plan), "kinds": kinds, "MSps_realtime": shape.fs / 1e6, "block_ms": round(1e3 * shape.L / shape.fs, 3),
+           "hand_over": "host waits for the transfer (KA9Q_HIP_STREAM_HOSTWAIT=1)" if os.environ.get("KA9Q_HIP_STREAM_HOSTWAIT", "1") != "0"
+                        else "front stream waits on the transfer's event"}
     # (a) unpaced, Tr blocks per submit: the PCIe-inclusive rate.  The producer's write into the pinned slot is included.
-    def unpaced(fill):
-        nsub = blocks // Tr
+    def unpaced(fill, n):
+        nsub = n // Tr
         for j in range(8):
             s = bank.stream_slot(0, np.int16, Tr * 2 * shape.L)
             bank.stream_submit(Tr)
@@ -234,40 +309,18 @@ def realtime_leg(pyka9q, torch, device, blocks=1000):
             s[b * 2 * shape.L:(b + 1) * 2 * shape.L] = raw[(k * Tr + b) % nsrc]
         bank.stream_submit(Tr)
     bank.sync()
-    tb = unpaced(False)
+    tb = unpaced(False, blocks if full else 200)
     res["pcie_inclusive"] = {"blocks_per_submit": Tr, "us_per_block": round(tb * 1e6, 2), "MSps": round(shape.L / tb / 1e6, 1),
                              "H2D_GBps": round(4 * shape.L / tb / 1e9, 2), "realtime_factor": round((shape.L / shape.fs) / tb, 1),
                              "note": "every submit crosses PCIe (pinned ring -> device raw ring); the producer's own write into the ring is not included"}
-    tf = unpaced(True)
-    res["pcie_inclusive_with_producer_copy"] = {"us_per_block": round(tf * 1e6, 2), "MSps": round(shape.L / tf / 1e6, 1),
-                                                "note": "as above plus a single-threaded numpy copy of every block into the pinned slot"}
+    if full:
+        tf = unpaced(True, blocks)
+        res["pcie_inclusive_with_producer_copy"] = {"us_per_block": round(tf * 1e6, 2), "MSps": round(shape.L / tf / 1e6, 1),
+                                                    "note": "as above plus a single-threaded numpy copy of every block into the pinned slot"}
     res["extrapolated_channels_at_realtime"] = int(len(plan) * (shape.L / shape.fs) / tb)
     # (b) paced: one block per submit, released at k * L / fs
-    pcm = np.empty((len(plan), shape.olen), np.int16)
-    period = shape.L / shape.fs
-    lat, late = [], 0
-    t0 = time.perf_counter() + 0.01
-    for k in range(blocks):
-        due = t0 + k * period
-        while True:
-            now = time.perf_counter()
-            if now >= due:
-                break
-            time.sleep(min(due - now, 0.002))
-        s = bank.stream_slot(0, np.int16, 2 * shape.L)
-        s[:] = raw[k % nsrc]
-        bank.stream_submit(1)
-        bank.pcm_all(1, pcm)
-        done = time.perf_counter()
-        lat.append(done - due)
-        if done > due + period:
-            late += 1
-    lat = np.array(lat)
-    res["paced"] = {"blocks": blocks, "blocks_per_submit": 1, "late_blocks": int(late), "holds_realtime": bool(late == 0),
-                    "latency_ms_release_to_pcm": {"mean": round(1e3 * float(lat.mean()), 3), "p99": round(1e3 * float(np.percentile(lat, 99)), 3),
-                                                  "max": round(1e3 * float(lat.max()), 3)},
-                    "busy_fraction": round(float(lat.mean()) / period, 4)}
-    res["channels_sustained_in_real_time"] = len(plan) if late == 0 else None
+    res["paced"] = paced_run(bank, shape, raw, nsrc, blocks, len(plan))
+    res["channels_sustained_in_real_time"] = len(plan) if res["paced"]["late_blocks"] == 0 else None
     bank.stream_close()
     bank.close()
     return res
@@ -417,12 +470,38 @@ def main():
         dt = float(tt.item())
 
     note(f"timed region done: {dt:.4f} s")
-    # per-kernel durations: the same K steps with a HIP event pair around every stage on the bank's stream
+    # a longer run of the same step (>= 0.5 s), so that the line carries a low-noise figure whatever --steps was
+    LONG_S = float(os.environ.get("KA9Q_BENCH_LONG_S", "0.5"))
+    n_long, t_long = 0, 0.0
+    if LONG_S > 0:
+        barrier()
+        tl = time.perf_counter()
+        while True:
+            for _ in range(200):
+                step()
+            n_long += 200
+            bank.sync()
+            t_long = time.perf_counter() - tl
+            if t_long >= LONG_S:
+                break
+        if dist is not None:
+            tt = torch.tensor([t_long / n_long], device=cdev, dtype=torch.float64)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            t_long = float(tt.item()) * n_long
+    # per-kernel durations, live, with HIP event pairs around every stage: (1) the same K steps with everything on one
+    # stream (each kernel alone on the chip), (2) the two-stream pipeline the timed region ran, the events of each stage on
+    # the stream it runs on (what the kernel takes beside the other half's kernels)
+    nprof = max(args.steps, 20)
     bank.profile(1)
-    for _ in range(args.steps):
+    for _ in range(nprof):
         step()
     bank.sync()
     st = bank.stage_times()
+    bank.profile(2)
+    for _ in range(nprof):
+        step()
+    bank.sync()
+    st_pipe = bank.stage_times()
     bank.profile(0)
 
     # SURVEY.md 8(e) / BASELINE configs[3]: every GPU recomputes the forward FFT of the shared stream (option A, what the
@@ -485,22 +564,31 @@ def main():
                     stages[name] = {"ms": round(avg, 5), "GBps": None, "empty": empty[name]}
                 else:
                     stages[name] = {"ms": round(avg, 5), "GBps": round(sb[name] / (avg * 1e-3) / 1e9, 1) if avg > 0 else None}
-        dom = max((k for k in stages if k != "carry" and k not in empty), key=lambda k: stages[k]["ms"])
+        for name, (ms, n) in st_pipe.items():  # the same stages inside the two-stream pipeline
+            if n and name in stages:
+                stages[name]["ms_pipelined"] = round(ms / n, 5)
+                if name not in empty and ms > 0:
+                    stages[name]["GBps_pipelined"] = round(sb[name] / (ms / n * 1e-3) / 1e9, 1)
+        # the dominant kernel is the one that takes longest in the run that was timed (the pipeline)
+        dom = max((k for k in stages if k != "carry" and k not in empty), key=lambda k: stages[k].get("ms_pipelined", stages[k]["ms"]))
         traffic = traffic_src = None  # HBM bytes per launch of that kernel from the committed PMC passes (profiles/, tools/summarize_prof.py)
         try:
             # (r0N_stepM_hbm_traffic.json: this command; the other r0N_* files are other shapes or switches)
             cands = sorted(glob.glob(os.path.join(ROOT, "profiles", "r0[2-9]_step[0-9]_hbm_traffic.json"))) or \
                 sorted(glob.glob(os.path.join(ROOT, "profiles", "r01_step8_hbm_traffic.json")))
             prof = json.load(open(cands[-1]))["kernels"]
-            key = {"fft1": "kh_fft_cols", "fft2": "kh_fft_rows", "chan": "kh_back_a", "demod": "kh_fm_finish_w", "n0": "kh_n0_pass1"}.get(dom)
-            hit = [v for k, v in prof.items() if key and key in k]
+            keys = {"fft1": ("kh_fft_cols",), "fft2": ("kh_fft_rows",), "chan": ("kh_chan2", "kh_back_a"),
+                    "demod": ("kh_fm_demod2", "kh_fm_finish_w"), "n0": ("kh_n0_pass1",)}.get(dom, ())
+            hit = [v for k, v in prof.items() if any(key in k for key in keys)]
             if hit and world == 1 and T == 32:
                 traffic = hit[0]["hbm_bytes_per_launch"]
                 traffic_src = os.path.relpath(cands[-1], ROOT) + " (separate rocprofv3 --pmc passes of this command)"
         except (OSError, ValueError, KeyError, IndexError):
             pass
-        dom_ms = stages[dom]["ms"]
+        dom_ms_alone = stages[dom]["ms"]
+        dom_ms = stages[dom].get("ms_pipelined", dom_ms_alone)
         achieved = sb[dom] / (dom_ms * 1e-3) / 1e9
+        achieved_alone = sb[dom] / (dom_ms_alone * 1e-3) / 1e9
         kernel_name = pyka9q.lib().kh_stage_kernel_name(pyka9q.KH_STAGES.index(dom)).decode()
         total_alg = SH.algorithmic_bytes(plan, T)  # BASELINE.md section 3 formula
         ms_per_step = 1e3 * dt / args.steps
@@ -528,10 +616,17 @@ def main():
             "pipeline_GBps_algorithmic": round(total_alg / (ms_per_step * 1e-3) / 1e9, 1),
             "pipeline_frac_of_hbm_peak": round(total_alg / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
             "stages": stages,
+            "value_long": round(world * n_long * T * L / t_long / 1e6, 2) if n_long else None,
+            "ms_per_step_long": round(1e3 * t_long / n_long, 4) if n_long else None,
+            "steps_long": n_long,
             "roofline": {"bound": "hbm", "kernel": kernel_name, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS,
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic,
                          "traffic_source": traffic_src,
-                         "algorithmic_bytes_per_launch": sb[dom], "avg_launch_ms": dom_ms},
+                         "algorithmic_bytes_per_launch": sb[dom], "avg_launch_ms": dom_ms,
+                         "measured": "HIP events around the kernel on its own stream inside the two-stream pipeline the value was timed in "
+                                     "(the longest stage there); *_alone: the same kernel with nothing beside it (one stream)",
+                         "frac_pipelined": round(achieved / HBM_PEAK_GBPS, 4), "frac_alone": round(achieved_alone / HBM_PEAK_GBPS, 4),
+                         "achieved_alone": round(achieved_alone, 1), "avg_launch_ms_alone": dom_ms_alone},
         }
         if probe is not None:
             fft_ms = sum(stages[k]["ms"] for k in ("ingest", "fft1", "fft2") if k in stages)
@@ -545,6 +640,19 @@ def main():
                 out["realtime"] = realtime_leg(pyka9q, torch, device)
             except Exception as e:
                 out["realtime"] = {"error": repr(e)}
+            # north_star's target shape on the hardware there is: all 4096 NBFM channels of the 64 MS/s stream on ONE GPU,
+            # paced at the stream's own block rate (radio.c:132-204, sizing main.c:326-330); and config 3's 1024 mixed channels
+            for key, shape, plan, label in (
+                    ("realtime_config4", workloads.CONFIG4, workloads.config4_plan(),
+                     "config 4 stream: 64 MS/s s16le (IQ_PT), N = 2^20, all 4096 NBFM 12.5 kHz channels on one GPU, pinned host ring -> "
+                     "hipMemcpyAsync -> launch, one 8.192 ms block per submit; PCM of every channel read back"),
+                    ("realtime_config3", workloads.CONFIG3, workloads.config3_plan(),
+                     "config 3 stream: 20 MS/s s16le, N = 2^19, all 1024 mixed channels (NBFM / envelope AM / USB) on one GPU, one "
+                     "13.1 ms block per submit; PCM of every channel read back")):
+                try:
+                    out[key] = realtime_leg(pyka9q, torch, device, shape, plan, label, blocks=1000, full=False)
+                except Exception as e:
+                    out[key] = {"error": repr(e)}
         if x_cpu is not None:
             out["cpu_baseline"] = cpu_baseline(x_cpu, rots)
         print(json.dumps(out), flush=True)

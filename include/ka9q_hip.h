@@ -415,7 +415,10 @@ int kh_hackrf_pack_noalloc(int payload, const float *ip, const float *qp, unsign
 /* diagnostic: one character per stream / event of the bank ('.' idle or complete, 'P' pending, 'E' error) */
 int kh_bank_debug_pending(kh_bank *, char *buf, size_t n);
 void *kh_bank_stream(kh_bank *); /* hipStream_t */
-/* per-kernel timing with HIP events on the bank's stream.  Stages: */
+/* per-kernel timing with HIP events.  kh_bank_profile(bank, 1): every stage alone on the chip (both halves on the
+ * bank's one stream, an event pair around every stage); 2: the normal two-stream pipeline with the same event pairs, each
+ * on the stream its stage runs on (what a stage takes beside the other half's kernels; the events themselves cost the
+ * step a few microseconds); 0: off.  Stages: */
 enum kh_stage { KH_STAGE_INGEST = 0, KH_STAGE_FFT1, KH_STAGE_FFT2, KH_STAGE_N0, KH_STAGE_CHAN, KH_STAGE_DEMOD,
                 KH_STAGE_CARRY, KH_STAGE_COUNT };
 int kh_bank_profile(kh_bank *, int enable);

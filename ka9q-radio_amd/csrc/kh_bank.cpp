@@ -127,6 +127,7 @@ struct kh_bank {
   struct GraphEntry {
     unsigned nblocks;
     int cur, fmpar, sp;
+    const void *raw;       // the raw ring the front half reads (kh_bank_stream_submit alternates between two)
     bool pipelined, fused;
     int seen;              // launches seen with this key; -1: capture failed, stay eager
     hipGraphExec_t front, back;
@@ -149,8 +150,13 @@ struct kh_bank {
   std::vector<hipEvent_t> ev_h2d;      // the transfer of submit k has completed
   std::vector<hipEvent_t> ev_raw_free; // the front half of submit k has read its device ring
   unsigned char *d_raw_buf[2] = {nullptr, nullptr}; // [0] is d_raw as created
-  // profiling
-  bool profiling = false;
+  // profiling: 1 = everything on one stream with an event pair around every stage (each kernel alone on the chip);
+  // 2 = the normal two-stream pipeline with the same event pairs, each on the stream its stage runs on (what a kernel
+  // takes beside the other half's kernels); the events of a launch are read when its slot comes round again
+  int profiling = 0;
+  hipEvent_t evp[MAX_SLOTS][KH_STAGE_COUNT + 2] = {};
+  bool evp_pending[MAX_SLOTS] = {};
+  hipEvent_t *cur_ev = nullptr; // the event set enqueue_front / enqueue_back record into
   hipEvent_t ev[KH_STAGE_COUNT + 2] = {};
   float stage_ms[KH_STAGE_COUNT] = {};
   unsigned stage_n[KH_STAGE_COUNT] = {};
@@ -189,6 +195,9 @@ int kh_bank_destroy(kh_bank *b) {
     if (p) hipFree(p);
   for (auto &e : b->ev)
     if (e) hipEventDestroy(e);
+  for (auto &set : b->evp)
+    for (auto &e : set)
+      if (e) hipEventDestroy(e);
   for (auto &e : b->idesc_ev)
     if (e) hipEventDestroy(e);
   if (b->h_idesc) hipHostFree(b->h_idesc);
@@ -568,14 +577,20 @@ int kh_bank_stream_open(kh_bank *b, unsigned int depth) {
   if (ok && !b->h_pcm) ok = KH_HIP(hipHostMalloc((void **)&b->h_pcm, (size_t)b->C * b->pcm_stride * sizeof(int16_t), hipHostMallocDefault));
   ok = ok && KH_HIP(hipHostGetDevicePointer((void **)&b->h_ring_dev, b->h_ring, 0));
   {
-    // at the highest priority: the runtime keeps the hardware queues of each priority apart, so the transfers do not
-    // share a queue with the compute streams whose launches wait for them (see kh_bank_stream_submit)
+    // at a priority of its own: the runtime maps streams to its few hardware queues by priority class, and a barrier
+    // packet of one stream holds up every stream that shares its queue.  The back stream is created at the greatest
+    // priority and the front stream at the least (kh_bank_create), so the copy stream takes the one between them and
+    // shares a queue with neither of the streams whose launches depend on its transfers.
     int least = 0, greatest = 0;
     ok = ok && KH_HIP(hipDeviceGetStreamPriorityRange(&least, &greatest));
+    int const own = (least - greatest >= 2) ? (least + greatest) / 2 : greatest;
     int const prio = getenv("KA9Q_HIP_STREAM_PRIO") ? atoi(getenv("KA9Q_HIP_STREAM_PRIO")) : 1;
     b->stream_sdma = getenv("KA9Q_HIP_STREAM_SDMA") ? atoi(getenv("KA9Q_HIP_STREAM_SDMA")) : 1;
-    b->stream_hostwait = getenv("KA9Q_HIP_STREAM_HOSTWAIT") ? atoi(getenv("KA9Q_HIP_STREAM_HOSTWAIT")) : 0;
-    ok = ok && (prio ? KH_HIP(hipStreamCreateWithPriority(&b->copy, hipStreamNonBlocking, greatest))
+    // 1 (default): the HOST waits for the transfer before it queues the launch, so no stream ever waits on another
+    // stream's event on account of the ring; the transfer of submit k+1 still runs beside the launch of submit k.
+    // 0: the front stream waits on the transfer's event.
+    b->stream_hostwait = getenv("KA9Q_HIP_STREAM_HOSTWAIT") ? atoi(getenv("KA9Q_HIP_STREAM_HOSTWAIT")) : 1;
+    ok = ok && (prio ? KH_HIP(hipStreamCreateWithPriority(&b->copy, hipStreamNonBlocking, own))
                      : KH_HIP(hipStreamCreateWithFlags(&b->copy, hipStreamNonBlocking)));
   }
   b->d_raw_buf[0] = b->d_raw;
@@ -587,6 +602,7 @@ int kh_bank_stream_open(kh_bank *b, unsigned int depth) {
   for (auto &e : b->ev_raw_free) ok = ok && KH_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
   b->stream_k = 0;
   b->stream_depth = depth;
+  drop_graphs(b); // (a captured front half has the raw ring's address baked in)
   if (!ok) {
     kh_bank_stream_close(b);
     return -1;
@@ -604,6 +620,7 @@ int kh_bank_stream_close(kh_bank *b) {
   for (auto &e : b->ev_raw_free)
     if (e) hipEventDestroy(e);
   b->ev_raw_free.clear();
+  drop_graphs(b);
   if (b->d_raw_buf[0]) b->d_raw = b->d_raw_buf[0]; // what kh_bank_destroy frees
   if (b->d_raw_buf[1]) hipFree(b->d_raw_buf[1]);
   b->d_raw_buf[0] = b->d_raw_buf[1] = nullptr;
@@ -654,7 +671,7 @@ int kh_bank_stream_submit(kh_bank *b, unsigned int nblocks) {
     return -1;
   if (!KH_HIP(hipEventRecord(b->ev_h2d[e], b->copy))) return -1;
   // the stream the front half takes (profiling passes and one-stream mode put it on the back stream) waits for the samples
-  hipStream_t const fs = (b->profiling || !b->pipeline) ? b->stream : b->front;
+  hipStream_t const fs = (b->profiling == 1 || !b->pipeline) ? b->stream : b->front;
   // (KA9Q_HIP_STREAM_HOSTWAIT=1: the host waits for the transfer instead, and no stream waits for another)
   if (b->stream_hostwait ? !KH_HIP(hipEventSynchronize(b->ev_h2d[e])) : !KH_HIP(hipStreamWaitEvent(fs, b->ev_h2d[e], 0))) return -1;
   b->d_raw = b->d_raw_buf[dev];
@@ -738,7 +755,7 @@ static int enqueue_front(kh_bank *b, hipStream_t st, unsigned int nblocks, bool 
   int const L = b->cfg.L, M = b->cfg.M, N = b->N, P = b->P, sp = b->sp;
   size_t const need = (size_t)nblocks * L;
   float2 *time = b->d_time[b->cur];
-  if (prof) hipEventRecord(b->ev[0], st);
+  if (prof) hipEventRecord(b->cur_ev[0], st);
   // the last M-1 samples of the launch are the next launch's overlap-save history (filter.c:230): ingest stores
   // them at the head of the other buffer as it goes, unless the history reaches back beyond this launch
   bool const fused_carry = (size_t)(M - 1) <= need;
@@ -750,7 +767,7 @@ static int enqueue_front(kh_bank *b, hipStream_t st, unsigned int nblocks, bool 
                               b->d_energy[sp], L, nblocks, P, fused_carry ? b->d_time[b->cur ^ 1] : nullptr,
                               need - (fused_carry ? (M - 1) : 0)))
     return -1;
-  if (prof) hipEventRecord(b->ev[1], st);
+  if (prof) hipEventRecord(b->cur_ev[1], st);
   // launch_forward_fft records the mid event (ev[2]) between the two passes itself
   N0Plan const plan = n0_plan(N, b->cfg.samprate, b->cfg.n0_low, b->cfg.n0_high);
   bool const n0_on = b->cfg.compute_n0 && plan.valid;
@@ -763,13 +780,13 @@ static int enqueue_front(kh_bank *b, hipStream_t st, unsigned int nblocks, bool 
     nf.spin = b->n0_spin;
   }
   if (launch_forward_fft(st, time, b->time_stride, 0, b->d_spec[sp], b->d_tmp, b->spec_stride, N, L, nblocks, P,
-                         prof ? b->ev[2] : nullptr, nf, fused ? &fi : nullptr))
+                         prof ? b->cur_ev[2] : nullptr, nf, fused ? &fi : nullptr))
     return -1;
   // overlap-save history for the next call (filter.c:230), into the other buffer
   if (!fused && !fused_carry && launch_carry(st, time + need, b->d_time[b->cur ^ 1], b->time_stride * sizeof(float2),
                                    (size_t)(M - 1) * sizeof(float2), P))
     return -1;
-  if (prof) hipEventRecord(b->ev[3], st);
+  if (prof) hipEventRecord(b->cur_ev[3], st);
   return 0;
 }
 static bool n0_in_fft(const kh_bank *b) {
@@ -807,11 +824,11 @@ static int enqueue_back(kh_bank *b, hipStream_t st, unsigned int nblocks, bool p
   if (!ride && launch_n0(st, n0spec, b->spec_stride, N, b->cfg.samprate, plan, b->d_energy[sp], echunks, L, b->d_n0state,
                          b->d_n0acc[sp], b->d_istatus, nblocks, P, in_fft ? 1 : 0, nullptr, dsync))
     return -1;
-  if (prof) hipEventRecord(b->ev[4], st);
+  if (prof) hipEventRecord(b->cur_ev[4], st);
   int taken = 0;
   // round 3's back half (kh_chan2 + kh_fm_snr_lanes + kh_fm_demod2) for N_dec = 512 / 1024; KA9Q_HIP_BACK2=0 and every
   // other shape take round 2's kernels
-  bool const back2 = fm2_usable(b->ND, b->olen, (int)nblocks) != 0;
+  bool const back2 = fm2_usable(b->ND, b->olen, (int)nblocks, b->n_fm) != 0;
   if (back2) {
     if (launch_chan2(st, b->d_spec[sp], b->spec_stride, N, b->d_chans, b->d_resp, b->ND, b->olen, b->d_bb, b->bb_stride, nblocks, C,
                      b->n_fm ? b->d_fmstat : nullptr, b->T, b->keep_baseband, ride ? &z : nullptr))
@@ -829,7 +846,7 @@ static int enqueue_back(kh_bank *b, hipStream_t st, unsigned int nblocks, bool p
   if (ride && launch_n0(st, n0spec, b->spec_stride, N, b->cfg.samprate, plan, b->d_energy[sp], echunks, L, b->d_n0state,
                         b->d_n0acc[sp], b->d_istatus, nblocks, P, taken, ride_final ? &nf : nullptr, dsync))
     return -1;
-  if (prof) hipEventRecord(b->ev[5], st);
+  if (prof) hipEventRecord(b->cur_ev[5], st);
   if (back2 && b->n_fm > 0 &&
       launch_fm2(st, b->d_bb, b->bb_stride, b->olen, nblocks, b->d_ddesc, b->d_dstate, b->keep_audio ? b->d_audio : nullptr, b->d_pcm,
                  b->pcm_stride, b->cfg.pcm_big_endian, b->d_status, b->T, b->d_lists, b->n_fm, b->d_fmstat, b->d_decaypow,
@@ -844,7 +861,7 @@ static int enqueue_back(kh_bank *b, hipStream_t st, unsigned int nblocks, bool p
   if (b->rtp && launch_rtp_plan(st, b->d_pcm, b->pcm_stride, b->olen, nblocks, C, b->d_ddesc, b->d_rtp, b->rtp_stride,
                                 b->d_rtpstate))
     return -1;
-  if (prof) hipEventRecord(b->ev[6], st);
+  if (prof) hipEventRecord(b->cur_ev[6], st);
   return 0;
 }
 
@@ -869,6 +886,28 @@ static int run_half(kh_bank *b, hipStream_t st, unsigned int nblocks, int (*half
   return KH_HIP(hipGraphLaunch(*exec, st)) ? 0 : -1;
 }
 
+// stage s = E[first[s]] .. E[first[s] + 1]; in the two-stream pipeline the n0 stage starts at the back half's own first
+// event (E[KH_STAGE_COUNT]): E[3] belongs to the other stream
+static void accumulate_stage_events(kh_bank *b, hipEvent_t *E, bool two_streams) {
+  static int const first[KH_STAGE_COUNT] = {0, 1, 2, 3, 4, 5, -1};
+  for (int s = 0; s < KH_STAGE_COUNT; s++) {
+    if (first[s] < 0) continue;
+    float ms = 0.f;
+    hipEvent_t const e0 = (two_streams && s == KH_STAGE_N0) ? E[KH_STAGE_COUNT] : E[first[s]];
+    if (hipEventElapsedTime(&ms, e0, E[first[s] + 1]) == hipSuccess) {
+      b->stage_ms[s] += ms;
+      b->stage_n[s]++;
+    }
+  }
+  (void)hipGetLastError();
+}
+static int collect_stage_events(kh_bank *b, int slot) {
+  if (!KH_HIP(hipEventSynchronize(b->evp[slot][6]))) return -1;
+  accumulate_stage_events(b, b->evp[slot], true);
+  b->evp_pending[slot] = false;
+  return 0;
+}
+
 int kh_bank_execute(kh_bank *b, unsigned int nblocks) {
   if (!b) return -1;
   if (nblocks == 0 || nblocks > (unsigned)b->T) {
@@ -884,7 +923,8 @@ int kh_bank_execute(kh_bank *b, unsigned int nblocks) {
       return -1;
     }
   if (b->chans_dirty && upload_channels(b)) return -1;
-  bool const prof = b->profiling;
+  bool const prof = b->profiling == 1;                  // every stage alone, one stream
+  bool const prof2 = b->profiling == 2 && b->pipeline;  // the two-stream pipeline, with events
   hipStream_t const sb = b->stream;                                // back half
   hipStream_t const sf = (prof || !b->pipeline) ? sb : b->front;   // front half
   int const sp = b->sp;
@@ -926,16 +966,26 @@ int kh_bank_execute(kh_bank *b, unsigned int nblocks) {
 
   int rc = 0;
   if (prof) {
+    b->cur_ev = b->ev;
     rc = enqueue_front(b, sf, nblocks, true);
     if (!rc) rc = enqueue_back(b, sb, nblocks, true);
+  } else if (prof2) {
+    if (b->evp_pending[sp] && collect_stage_events(b, sp)) return -1; // (this slot's launch of nslots launches ago)
+    b->cur_ev = b->evp[sp];
+    rc = enqueue_front(b, sf, nblocks, true);
+    if (!rc && (!KH_HIP(hipEventRecord(b->ev_front_done[sp], sf)) || !KH_HIP(hipStreamWaitEvent(sb, b->ev_front_done[sp], 0)) ||
+                !KH_HIP(hipEventRecord(b->evp[sp][KH_STAGE_COUNT], sb)))) // back half may start: the n0 stage's first event
+      rc = -1;
+    if (!rc) rc = enqueue_back(b, sb, nblocks, true);
+    if (!rc) b->evp_pending[sp] = true;
   } else {
     kh_bank::GraphEntry *g = nullptr;
     for (auto &x : b->graphs)
-      if (x.nblocks == nblocks && x.cur == b->cur && x.fmpar == b->fm_parity && x.sp == sp && x.pipelined == (sf != sb) &&
-          x.fused == b->fused_now)
+      if (x.nblocks == nblocks && x.cur == b->cur && x.fmpar == b->fm_parity && x.sp == sp && x.raw == b->d_raw &&
+          x.pipelined == (sf != sb) && x.fused == b->fused_now)
         g = &x;
     if (!g) { // first sight: run eagerly (this also warms the twiddle tables, which allocate)
-      b->graphs.push_back(kh_bank::GraphEntry{nblocks, b->cur, b->fm_parity, sp, sf != sb, b->fused_now, 0, nullptr, nullptr});
+      b->graphs.push_back(kh_bank::GraphEntry{nblocks, b->cur, b->fm_parity, sp, b->d_raw, sf != sb, b->fused_now, 0, nullptr, nullptr});
       g = &b->graphs.back();
     }
     rc = run_half(b, sf, nblocks, enqueue_front, &g->front, g->seen);
@@ -985,14 +1035,7 @@ int kh_bank_execute(kh_bank *b, unsigned int nblocks) {
   b->last_blocks = nblocks;
   if (prof) {
     if (!KH_HIP(hipStreamSynchronize(sb))) return -1;
-    static int const first[KH_STAGE_COUNT] = {0, 1, 2, 3, 4, 5, -1}; // stage s = ev[first[s]] .. ev[first[s]+1]
-    for (int s = 0; s < KH_STAGE_COUNT; s++) {
-      float ms = 0.f;
-      if (first[s] >= 0 && hipEventElapsedTime(&ms, b->ev[first[s]], b->ev[first[s] + 1]) == hipSuccess) {
-        b->stage_ms[s] += ms;
-        b->stage_n[s]++;
-      }
-    }
+    accumulate_stage_events(b, b->ev, false);
   }
   return 0;
 }
@@ -1099,14 +1142,22 @@ int kh_bank_use_graph(kh_bank *b, int enable) {
 }
 int kh_bank_profile(kh_bank *b, int enable) {
   if (!b) return -1;
-  if (kh_bank_sync(b)) return -1; // the two modes order their work differently
-  b->profiling = enable != 0;
+  if (kh_bank_sync(b)) return -1; // the modes order their work differently
+  if (enable < 0 || enable > 2) return -1;
+  for (int k = 0; k < kh_bank::MAX_SLOTS; k++) b->evp_pending[k] = false;
+  if (enable == 2)
+    for (auto &set : b->evp)
+      for (auto &e : set)
+        if (!e && !KH_HIP(hipEventCreate(&e))) return -1;
+  b->profiling = enable;
   memset(b->stage_ms, 0, sizeof(b->stage_ms));
   memset(b->stage_n, 0, sizeof(b->stage_n));
   return 0;
 }
 int kh_bank_stage_times(kh_bank *b, float ms[KH_STAGE_COUNT], unsigned int launches[KH_STAGE_COUNT]) {
   if (!b) return -1;
+  for (int k = 0; k < kh_bank::MAX_SLOTS; k++)
+    if (b->evp_pending[k] && collect_stage_events(b, k)) return -1;
   for (int s = 0; s < KH_STAGE_COUNT; s++) {
     if (ms) ms[s] = b->stage_ms[s];
     if (launches) launches[s] = b->stage_n[s];
@@ -1119,8 +1170,8 @@ const char *kh_stage_kernel_name(int stage) {
   case KH_STAGE_FFT1: return "kh_fft_cols|kh_fft_fwd_lds";    // first (or only) pass of the forward transform
   case KH_STAGE_FFT2: return "kh_fft_rows";
   case KH_STAGE_N0: return "kh_n0_pass1+kh_n0_final";         // zero when the second iteration rides in kh_back_a
-  case KH_STAGE_CHAN: return "kh_back_a|kh_chan_wave64|kh_filter_out";
-  case KH_STAGE_DEMOD: return "kh_fm_finish_w|kh_demod_linear|kh_demod_am";
+  case KH_STAGE_CHAN: return "kh_chan2|kh_back_a|kh_chan_wave64|kh_filter_out";
+  case KH_STAGE_DEMOD: return "kh_fm_demod2|kh_fm_finish_w|kh_demod_linear|kh_demod_am";
   case KH_STAGE_CARRY: return "kh_carry";
   }
   return "";

@@ -929,7 +929,7 @@ int launch_filter_output(hipStream_t st, const float2 *spec, size_t spec_in_stri
   static int const wave_env = getenv("KA9Q_HIP_CHAN_WAVE") ? atoi(getenv("KA9Q_HIP_CHAN_WAVE")) : 1; // A/B switch
   if (wave_env && complex_out && !in_real && chan_wave_supported(ND, olen)) {
     if (n0_taken) *n0_taken = n0 != nullptr;
-    if (fm.stat == nullptr && fm2_usable(ND, olen, nblocks)) // no FM epilogue wanted: the 32-points-per-lane form
+    if (fm.stat == nullptr && fm2_usable(ND, olen, nblocks, 0)) // no FM epilogue wanted: the 32-points-per-lane form
       return launch_chan2(st, spec, spec_in_stride, N, chans, response, ND, olen, static_cast<float2 *>(out), out_stride, nblocks,
                           nchan, nullptr, 0, 1, n0);
     return launch_chan_wave(st, spec, spec_in_stride, N, chans, response, ND, olen, static_cast<float2 *>(out), out_stride,

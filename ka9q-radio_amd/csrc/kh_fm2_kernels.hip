@@ -138,15 +138,20 @@ __global__ __launch_bounds__(1024) void kh_fm_demod2(Fm2Args F, int nfm_wg, N0Fi
   double const Ablk = F.decay_pow[OLEN];
   double const dpl = F.decay_pow[K * l]; // decay^(K l)
   const float2 *bbc = F.bb + (size_t)ch * F.bb_stride;
-  // ---- fm.c:69-70: the Rice-corrected SNR of every block of the launch, a lane each (wavefront 0; the others wait)
-  if (wave == 0) {
-    float const r = lane64 < nblocks ? fs[lane64].snr : 0.f; // kh_chan2 left avg^2 / variance there
-    for (int k = lane64; k < KH_XI_SEGS * (KH_XI_DEG + 1); k += 64) sh_coef[k] = (&kh_xi_coeffs[0][0])[k];
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    float const snr = fmaxf(0.0f, (float)fm_snr_lane((double)r, sh_coef));
-    if (lane64 < nblocks) sh_snr[lane64] = snr;
+  // ---- fm.c:69-70: the Rice-corrected SNR of every block of the launch, a lane each, dealt round-robin over the
+  // workgroup's wavefronts: a wavefront iterates as long as its slowest lane, and the blocks of idle channels sit at
+  // fm_snr's threshold where the round count varies most (0 .. 65), so few lanes per wavefront finish sooner
+  {
+    int const nwv = blockDim.x >> 6;
+    for (int k = threadIdx.x; k < KH_XI_SEGS * (KH_XI_DEG + 1); k += blockDim.x) sh_coef[k] = (&kh_xi_coeffs[0][0])[k];
+    int const per = (nblocks + nwv - 1) / nwv;           // lanes in use per wavefront
+    int const bs = lane64 < per ? lane64 * nwv + wave : nblocks;
+    float const r = bs < nblocks ? fs[bs].snr : 0.f;     // kh_chan2 left avg^2 / variance there
+    __syncthreads();
+    if (lane64 < per) { // (wave-uniform bound; lanes beyond the launch's blocks carry r = 0 and leave at once)
+      float const snr = fmaxf(0.0f, (float)fm_snr_lane((double)r, sh_coef));
+      if (bs < nblocks) sh_snr[bs] = snr;
+    }
   }
   __syncthreads();
   double c_pass = (double)lastaudio_in; // lastaudio on entry to the pass's first block
@@ -383,9 +388,15 @@ __global__ __launch_bounds__(1024) void kh_fm_demod2(Fm2Args F, int nfm_wg, N0Fi
   }
 }
 
-int fm2_usable(int ND, int olen, int nblocks) {
-  static int const env = getenv("KA9Q_HIP_BACK2") ? atoi(getenv("KA9Q_HIP_BACK2")) : 1; // A/B switch: 0 = round 2's kernels
-  return env && chan_wave_supported(ND, olen) && nblocks >= 1 && nblocks <= FM2_MAXT;
+// KA9Q_HIP_BACK2=0: round 2's kernels (kh_back_a + kh_fm_finish_w), the A/B reference.  One path for every bank size on
+// purpose: a channel's PCM then does not depend on how many channels share its bank, i.e. on how a band is sharded over
+// GPUs (tests/test_gpu_configs.py::test_config4_full_size_properties).  What that costs: a workgroup per channel keeps
+// only as many CUs busy as there are FM channels, so at configs[1] (64 channels x 32 open blocks) the demodulator stage
+// takes ~20 us against 13 us for round 2's wavefront per (channel, block); the step there is bound by the front half.
+int fm2_usable(int ND, int olen, int nblocks, int n_fm) {
+  (void)n_fm;
+  static int const env = getenv("KA9Q_HIP_BACK2") ? atoi(getenv("KA9Q_HIP_BACK2")) : 1;
+  return env != 0 && chan_wave_supported(ND, olen) && nblocks >= 1 && nblocks <= FM2_MAXT;
 }
 
 // n0final (may be null): kh_n0_final's work rides in the launch
@@ -402,15 +413,18 @@ int launch_fm2(hipStream_t st, const float2 *baseband, size_t bb_stride, int ole
   Fm2Args const F{nblocks, desc, state, parity, stat, status_stride, baseband, bb_stride, decay_pow, audio, pcm, pcm_stride,
                   pcm_big_endian, static_cast<kh_status *>(status), status_stride, fm_list};
   int const G = olen / 8, ppw = 64 / G;
-  // wavefronts per channel: enough of them chip-wide to hide each other's memory round trips (~8 per SIMD), but no more --
-  // every workgroup pays its own chain of dependent loads (list -> descriptor, state -> statistics) and the SNR iteration
-  // before its first block, so a large bank is better served by few wavefronts that walk a channel's blocks in passes
+  // wavefronts per channel: as many as keep every channel's workgroup resident at once (92 VGPRs: 5 wavefronts per SIMD,
+  // 5120 on the chip) -- a workgroup is a chain of dependent round trips (list -> descriptor, state -> statistics -> SNR
+  // iteration -> blocks in passes), so a second round of workgroups doubles the stage, while more passes per workgroup
+  // only lengthen it by the passes; then the fewest wavefronts that still need that many passes
   static int const nw_env = getenv("KA9Q_HIP_FM2_WAVES") ? atoi(getenv("KA9Q_HIP_FM2_WAVES")) : 0;
-  int nw = nw_env > 0 ? nw_env : (8192 + n_fm - 1) / n_fm;
-  int const nw_blocks = (nblocks + ppw - 1) / ppw;
-  if (nw > nw_blocks) nw = nw_blocks;
+  int const nw_blocks = (nblocks + ppw - 1) / ppw; // wavefronts that hold every block at once
+  int nw = nw_env > 0 ? nw_env : 5120 / n_fm;
   if (nw > FM2_MAXBP / ppw) nw = FM2_MAXBP / ppw; // at most 16 blocks per pass
+  if (nw > nw_blocks) nw = nw_blocks;
   if (nw < 1) nw = 1;
+  int const passes = (nw_blocks + nw - 1) / nw;
+  nw = (nw_blocks + passes - 1) / passes;
   dim3 const grid(n_fm + (n0final ? n0final->ninputs : 0));
   if (G == 32)
     hipLaunchKernelGGL(kh_fm_demod2<32>, grid, dim3(64 * nw), 0, st, F, n_fm, Z);

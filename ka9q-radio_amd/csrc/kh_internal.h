@@ -226,7 +226,7 @@ int launch_demod(hipStream_t st, float2 *baseband, size_t bb_stride, int olen, i
 int fm_finish_wave_usable(int olen, int nblocks);
 // round 3's FM path behind launch_chan2 (kh_fm2_kernels.hip): kh_fm_snr_lanes + kh_fm_demod2.  stat: what launch_chan2
 // left, [channel][status_stride]; n0final (may be null) rides in the first of the two launches
-int fm2_usable(int ND, int olen, int nblocks);
+int fm2_usable(int ND, int olen, int nblocks, int n_fm);
 int launch_fm2(hipStream_t st, const float2 *baseband, size_t bb_stride, int olen, int nblocks, const DemodDesc *desc,
                DemodState *state, float *audio, int16_t *pcm, size_t pcm_stride, int pcm_big_endian, void *status,
                int status_stride, const int *fm_list, int n_fm, FmBlockStat *stat, const double *decay_pow, int parity,

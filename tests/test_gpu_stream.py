@@ -13,7 +13,9 @@ pytestmark = pytest.mark.gpu
 @pytest.mark.parametrize("payload_name,depth,env", [
     ("KH_PT_IQ16LE", 2, {}), ("KH_PT_IQ16LE", 4, {}), ("KH_PT_CF32", 3, {}),
     ("KH_PT_IQ16LE", 3, {"KA9Q_HIP_STREAM_SDMA": "0"}),      # kh_host_pull instead of hipMemcpyAsync
-    ("KH_PT_CF32", 2, {"KA9Q_HIP_STREAM_HOSTWAIT": "1"}),    # the host, not the front stream, waits for the transfer
+    # (KA9Q_HIP_STREAM_HOSTWAIT=0 -- the front stream instead of the host waits for the transfer -- is a diagnostic switch
+    # and not part of the suite: on ROCm 7.2 that hand-over stalled for ~20 s in one run of this test and, with the copy
+    # stream in the back stream's priority class, for good: DESIGN.md section 9)
     ("KH_PT_IQ16LE", 2, {"KA9Q_HIP_PIPELINE": "0"}),         # one compute stream
 ])
 def test_stream_matches_write_input(hip, monkeypatch, payload_name, depth, env):
