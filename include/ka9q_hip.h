@@ -343,7 +343,10 @@ int kh_afsk_sync(kh_afsk *);
 int kh_afsk_read_frames(kh_afsk *, unsigned int session, struct kh_ax25_frame *out, size_t max, size_t *n);
 int kh_afsk_read_bits(kh_afsk *, unsigned int session, struct kh_afsk_bit *out, size_t max, size_t *n);
 int kh_afsk_read_status(kh_afsk *, unsigned int session, struct kh_afsk_status *out);
-int kh_afsk_read_baseband(kh_afsk *, unsigned int session, kh_cf32 *out, size_t nsamples); /* analytic signal, last launch */
+int kh_afsk_read_baseband(kh_afsk *, unsigned int session, kh_cf32 *out, size_t nsamples);
+/* diagnostic (no counterpart in packet.c): the tone products of the last launch, 4 floats per sample {Re, Im of y x mark,
+ * Re, Im of y x space} -- what the decoder's integrate-and-dump accumulators (packet.c:442-451) add up */
+int kh_afsk_read_products(kh_afsk *, unsigned int session, float *out, size_t nsamples); /* analytic signal, last launch */
 
 /* ---- pl.c: CTCSS ("PL") tone and DTMF decoders for many 48 kS/s mono PCM sessions.
  * The reference steps 55 + 8 tone oscillators per audio sample per session and looks at the integrators every 250 ms

@@ -73,6 +73,7 @@ struct kh_bank {
   int fused_ingest = 1;   // policy (KA9Q_HIP_FUSED_INGEST)
   int ride_n0 = 1;        // policy (KA9Q_HIP_RIDE_N0)
   int n0_direct_mode = -1; // policy (KA9Q_HIP_N0_DIRECT): 0 never, 1 whenever possible, -1 (default) by transform size
+  int n0_stagger = 0;      // KA9Q_HIP_N0_STAGGER (N0Fuse::stagger)
   int n0_spin = 1000;      // KA9Q_HIP_N0_SPIN: polls before a row-pass workgroup gives up (0: every block is re-read)
   bool fused_now = false; // this launch: large transform and no oscillator active
   // device
@@ -347,6 +348,7 @@ kh_bank *kh_bank_create(const struct kh_bank_config *cfg) {
   if (const char *e = getenv("KA9Q_HIP_RIDE_N0")) b->ride_n0 = atoi(e);
   if (const char *e = getenv("KA9Q_HIP_N0_DIRECT")) b->n0_direct_mode = atoi(e);
   if (const char *e = getenv("KA9Q_HIP_N0_SPIN")) b->n0_spin = std::min(std::max(atoi(e), 0), 100000);
+  if (const char *e = getenv("KA9Q_HIP_N0_STAGGER")) b->n0_stagger = std::min(std::max(atoi(e), 0), 64);
   b->chans.assign(C, ChanDesc{0, 0, COMPLEX, 0});
   b->ddesc.assign(C, DemodDesc{});
   b->ccfg.assign(C, kh_channel_config{});
@@ -778,6 +780,7 @@ static int enqueue_front(kh_bank *b, hipStream_t st, unsigned int nblocks, bool 
     nf.sync = reinterpret_cast<unsigned *>(b->d_n0acc[sp] + PT * (N0_SLOTS + 2 * N0_GX));
     nf.direct = 1;
     nf.spin = b->n0_spin;
+    nf.stagger = b->n0_stagger;
   }
   if (launch_forward_fft(st, time, b->time_stride, 0, b->d_spec[sp], b->d_tmp, b->spec_stride, N, L, nblocks, P,
                          prof ? b->cur_ev[2] : nullptr, nf, fused ? &fi : nullptr))

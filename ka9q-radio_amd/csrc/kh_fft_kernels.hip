@@ -456,6 +456,9 @@ __global__ __launch_bounds__(NT, 4) void kh_fft_rows(const float2 *__restrict__ 
   int const tile = blockIdx.x, bl = blockIdx.y, b = b0 + bl, i = blockIdx.z; // (b0, nblocks: as in kh_fft_cols)
   size_t const N = (size_t)R * N1;
   const float2 *src = tmp + i * spec_in_stride + (size_t)bl * N + (size_t)tile * W * R;
+  if constexpr (DIRECT) { // (experiment, KA9Q_HIP_N0_STAGGER: see the rendezvous below)
+    for (int k = (bl & 7) * n0.stagger; k > 0; k--) __builtin_amdgcn_s_sleep(8);
+  }
   float2 v[I1][RA];
 #pragma unroll
   for (int u = 0; u < I1; u++) { // lanes run along the row: RB consecutive points, then the next row

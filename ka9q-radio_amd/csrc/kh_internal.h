@@ -148,6 +148,7 @@ struct N0Fuse {
   unsigned *sync = nullptr;
   int direct = 0;
   int spin = 1000; // polls of ~0.1 us before a workgroup gives up (KA9Q_HIP_N0_SPIN; 0 sends every block to the re-read)
+  int stagger = 0; // direct mode: a workgroup of block b starts (b mod 8) * stagger * ~0.25 us late (KA9Q_HIP_N0_STAGGER; see kh_fft_rows)
 };
 constexpr int N0_SYNC_STRIDE = 64; // 32-bit words per (input, block) in N0Fuse::sync: lines of its own
 int n0_partials(int N);

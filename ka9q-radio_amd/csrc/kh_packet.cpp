@@ -265,6 +265,21 @@ int kh_afsk_read_baseband(kh_afsk *a, unsigned int session, kh_cf32 *out, size_t
   return 0;
 }
 
+// diagnostic: the tone products of the last launch, 4 floats per sample {Re, Im of y x mark, Re, Im of y x space}
+// (kh_afsk_mix): what kh_afsk_decode's accumulators add up.  The sweeps replay packet.c:440-545 over them.
+int kh_afsk_read_products(kh_afsk *a, unsigned int session, float *out, size_t nsamples) {
+  if (!session_ok(a, session, "kh_afsk_read_products") || !out) return -1;
+  if (nsamples > (size_t)a->last_T * kh_afsk::L) {
+    set_error("kh_afsk_read_products: the last launch produced %zu samples", (size_t)a->last_T * kh_afsk::L);
+    return -1;
+  }
+  if (!KH_HIP(hipMemcpyAsync(out, a->d_ms + session * a->y_stride, nsamples * sizeof(float4), hipMemcpyDeviceToHost,
+                             a->stream)) ||
+      !KH_HIP(hipStreamSynchronize(a->stream)))
+    return -1;
+  return 0;
+}
+
 } // extern "C"
 
 // ================================================================ pl.c: CTCSS and DTMF decoders

@@ -40,7 +40,14 @@ __device__ __forceinline__ int crc_good_dev(const unsigned char *frame, int leng
   return crc == 0xf0b8;
 }
 
-__device__ __forceinline__ float nrm(float2 v) { return v.x * v.x + v.y * v.y; } // cnrmf, dsp.h:65
+// cnrmf, dsp.h:65.  Two products and a sum, each rounded (no fused multiply-add): the bit clock steps on the SIGN of a
+// difference of two of these (packet.c:469), and with every operation a plain IEEE one the loop can be replayed
+// operation for operation on a host (tools/fuzz_afsk.py's referee over the device's own products)
+__device__ __forceinline__ float nrm(float2 v) {
+#pragma clang fp contract(off)
+  float const a = v.x * v.x, b = v.y * v.y;
+  return a + b;
+}
 
 // packet.c:445,449: s = filter->output.c[n] * step_osc(&mark|&space) for every sample of the launch, all of them at
 // once.  step_osc returns exp(2 pi i f n) for the n-th sample of the session (packet.c:410-419: both oscillators start

@@ -32,7 +32,7 @@ EXPORTS = [
     "kh_stage_kernel_name", "kh_bank_rtp_enable", "kh_bank_rtp_set_state", "kh_bank_read_rtp",
     "kh_afsk_create", "kh_afsk_destroy", "kh_afsk_write_pcm", "kh_afsk_pcm_device_ptr", "kh_afsk_commit_pcm",
     "kh_afsk_execute", "kh_afsk_sync", "kh_afsk_read_frames", "kh_afsk_read_bits", "kh_afsk_read_status",
-    "kh_afsk_read_baseband",
+    "kh_afsk_read_baseband", "kh_afsk_read_products",
     "kh_tones_create", "kh_tones_destroy", "kh_tones_write_pcm", "kh_tones_pcm_device_ptr", "kh_tones_commit_pcm",
     "kh_tones_execute", "kh_tones_sync", "kh_tones_read_pl", "kh_tones_read_dtmf",
     "kh_hackrf_correct", "kh_funcube_correct", "kh_hackrf_pack", "kh_hackrf_pack_noalloc",
@@ -202,6 +202,7 @@ def lib():
     L.kh_afsk_read_bits.argtypes = [C.c_void_p, C.c_uint, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]
     L.kh_afsk_read_status.argtypes = [C.c_void_p, C.c_uint, C.c_void_p]
     L.kh_afsk_read_baseband.argtypes = [C.c_void_p, C.c_uint, C.c_void_p, C.c_size_t]
+    L.kh_afsk_read_products.argtypes = [C.c_void_p, C.c_uint, C.c_void_p, C.c_size_t]
     L.kh_tones_create.restype = C.c_void_p
     L.kh_tones_create.argtypes = [C.c_uint, C.c_uint]
     L.kh_tones_destroy.argtypes = [C.c_void_p]
@@ -562,6 +563,12 @@ class Afsk:
     def baseband(self, session, nblocks):
         out = np.empty(nblocks * self.L, np.complex64)
         _check(self.lib.kh_afsk_read_baseband(self.h, session, out.ctypes.data, out.size), "kh_afsk_read_baseband")
+        return out
+
+    def products(self, session, nblocks):
+        """tone products of the last launch [nblocks*L, 4] (kh_afsk_mix): what the decoder's accumulators add up"""
+        out = np.empty((nblocks * self.L, 4), np.float32)
+        _check(self.lib.kh_afsk_read_products(self.h, session, out.ctypes.data, nblocks * self.L), "kh_afsk_read_products")
         return out
 
     def close(self):

