@@ -204,7 +204,9 @@ def back_half_ceilings(shape, plan, nblocks, st_alone, st_pipe, valu_key):
     try:
         counts = json.load(open(os.path.join(ROOT, "profiles", "r03_valu_counts.json")))[valu_key]
         insts = sum(k["SQ_INSTS_VALU"] for k in counts["kernels"].values())
-        bound_us = insts * 4 / SIMDS / CLOCK_HZ * 1e6
+        # a launch with fewer wavefronts than the chip has SIMDs can only issue on as many SIMDs as it has wavefronts
+        # (config 5's PLL kernel: 4 wavefronts, one lane per pipeline)
+        bound_us = sum(k["SQ_INSTS_VALU"] * 4 / min(SIMDS, max(1.0, k["SQ_WAVES"])) for k in counts["kernels"].values()) / CLOCK_HZ * 1e6
         out["roofline_valu"] = {"bound": "valu_issue", "SQ_INSTS_VALU_per_launch": int(insts), "kernels": sorted(counts["kernels"]),
                                 "issue_bound_us": round(bound_us, 1), "source": counts["source"],
                                 "frac_alone": round(bound_us / out["us_alone"], 4) if out.get("us_alone") else None,
@@ -360,14 +362,44 @@ def cpu_baseline(x_host, rots, budget_s=10.0):
                 break
     except OSError:
         pass
+    def run_replicas(n, budget):
+        """the reference's own way to more cores: several `radio` processes share one multicast I/Q stream, each with its
+        own forward FFT and its own channels (README.md:383-390).  Here: n pipelines, the channels dealt over
+        them, every one consuming the whole stream on a thread of its own (the C calls release the GIL); the stream
+        is sustained at the rate of the slowest replica."""
+        from concurrent.futures import ThreadPoolExecutor
+        groups = [g for g in np.array_split(np.arange(len(rots)), n) if len(g)]
+        pipes = []
+        for g in groups:
+            pipe = pipeline.Pipeline(L, M, D, FS, compute_n0=True, n0_low=-5500.0, n0_high=5500.0, fast=True, threads=1)
+            for j in g:
+                pipe.add_channel(demod="fm", rotate=rots[j], low=-5500.0, high=5500.0, kaiser_beta=3.0)
+            pipes.append(pipe)
+        nb_avail = x_host.size // L
+        t0 = time.perf_counter()
+
+        def work(pipe):
+            nb = 0
+            while time.perf_counter() - t0 < budget:
+                k = nb % nb_avail
+                pipe.run_block([x_host[k * L:(k + 1) * L]])
+                nb += 1
+            return nb, time.perf_counter() - t0
+        with ThreadPoolExecutor(max_workers=len(pipes)) as pool:
+            res = list(pool.map(work, pipes))
+        rate = min(nb / dt for nb, dt in res)  # blocks per second every replica has kept up with
+        return rate, len(pipes), sum(nb for nb, _ in res), max(dt for _, dt in res)
+
     nb1, dt1 = run(1, budget_s)
-    nbn, dtn = run(cores, budget_s)
+    rate_n, nrep, nbn, dtn = run_replicas(cores, budget_s)
     return {"value": round(nb1 * L / dt1 / 1e6, 3), "unit": "MS/s", "cores": 1, "kind": "port",
             "sample": f"{nb1} blocks of {L} samples, {C} NBFM channels, {dt1:.1f} s of CPU time",
             "ms_per_block": round(1e3 * dt1 / nb1, 3),
-            "all_cores": {"value": round(nbn * L / dtn / 1e6, 3), "unit": "MS/s", "cores": cores,
-                          "sample": f"{nbn} blocks, channels partitioned over {cores} threads, one shared forward FFT per block, {dtn:.1f} s",
-                          "ms_per_block": round(1e3 * dtn / nbn, 3)},
+            "all_cores": {"value": round(rate_n * L / 1e6, 3), "unit": "MS/s", "cores": nrep,
+                          "sample": f"{nrep} replicas of the pipeline (the reference's model: one `radio` process per group of channels, each "
+                                    f"with its own forward FFT), {C // nrep}-{-(-C // nrep)} channels each, all consuming the same stream; "
+                                    f"{nbn} blocks in all, {dtn:.1f} s",
+                          "ms_per_block": round(1e3 / rate_n, 3)},
             "cpu_model": model, "nproc_machine": os.cpu_count(),
             "compiler": "gcc -O3 -DNDEBUG=1 -funsafe-math-optimizations (the reference's COPTS, Makefile:2, without -march=native); own radix-2/3/5/7 FFT, no FFTW"}
 
@@ -525,10 +557,38 @@ def main():
                 v = torch.tensor([(time.perf_counter() - tb) / reps], device=cdev, dtype=torch.float64)
                 dist.all_reduce(v, op=dist.ReduceOp.MAX)
                 return round(1e3 * float(v.item()), 4)
+            def sliced_ms(spec, per_peer):
+                """SURVEY.md 8(e) option C-sliced: the root has the step's spectrum and sends every peer only the contiguous
+                bin slice its channels read (N / world bins + an N_dec halo, all T blocks): grouped point-to-point sends,
+                one per peer, in flight together (on xGMI: one link each)"""
+                recv = torch.empty(per_peer, 2, device=cdev, dtype=torch.float32)
+
+                def once():
+                    if rank == 0:
+                        ops = [dist.P2POp(dist.isend, spec[(r * per_peer) % (spec.shape[0] - per_peer):][:per_peer], r) for r in range(1, world)]
+                    else:
+                        ops = [dist.P2POp(dist.irecv, recv, 0)]
+                    for w in dist.batch_isend_irecv(ops):
+                        w.wait()
+                for _ in range(3):
+                    once()
+                torch.cuda.synchronize()
+                dist.barrier()
+                torch.cuda.synchronize()
+                tb = time.perf_counter()
+                reps = 10
+                for _ in range(reps):
+                    once()
+                torch.cuda.synchronize()
+                v = torch.tensor([(time.perf_counter() - tb) / reps], device=cdev, dtype=torch.float64)
+                dist.all_reduce(v, op=dist.ReduceOp.MAX)
+                return round(1e3 * float(v.item()), 4)
             raw_like = (x if rank == 0 else torch.empty_like(x)).to(cdev)
             spec_like = torch.empty(T * N, 2, device=cdev, dtype=torch.float32)
+            per_peer = T * (N // world + ND)
             probe = {"broadcast_input_ms": bcast_ms(raw_like), "input_bytes": int(raw_like.numel() * 4),
-                     "broadcast_spectrum_ms": bcast_ms(spec_like), "spectrum_bytes": int(spec_like.numel() * 4)}
+                     "broadcast_spectrum_ms": bcast_ms(spec_like), "spectrum_bytes": int(spec_like.numel() * 4),
+                     "sliced_spectrum_ms": sliced_ms(spec_like, per_peer), "sliced_bytes_per_peer": int(per_peer * 8)}
             del spec_like
         except Exception as e:  # the probe must never cost the bench line
             probe = {"error": repr(e)}
@@ -547,16 +607,19 @@ def main():
 
     if rank == 0:
         bincount = N - (int((N * 5500.0) / FS) - int((N * -5500.0) / FS))
-        # compute_n0's second iteration shares kh_back_a's launch for this shape (kh_bank.cpp enqueue_back)
+        # compute_n0's second iteration: in the row pass itself (direct mode, the default for four-step transforms); with
+        # KA9Q_HIP_N0_DIRECT=0 it re-reads the spectrum inside the channel kernel's launch (kh_bank.cpp enqueue_back)
         n0_rides = (ND == 1024 and 2 * OLEN == ND and os.environ.get("KA9Q_HIP_RIDE_N0", "1") != "0"
-                    and os.environ.get("KA9Q_HIP_CHAN_WAVE", "1") != "0" and os.environ.get("KA9Q_HIP_N0_DIRECT", "-1") != "1")
+                    and os.environ.get("KA9Q_HIP_CHAN_WAVE", "1") != "0" and os.environ.get("KA9Q_HIP_N0_DIRECT", "-1") == "0")
         sb = stage_bytes(bincount, n0_rides)
         stages = {}
         # stages whose work rides in another kernel still record an (empty) event pair of ~5 us: no rate for those
         fused_ingest = N > 8192 and os.environ.get("KA9Q_HIP_FUSED_INGEST", "1") != "0"
         empty = {"ingest": "in fft1 (kh_fft_cols reads the raw ring)"} if fused_ingest else {}
         if n0_rides:
-            empty["n0"] = "iteration 1 in chan (kh_back_a), final sums in demod (kh_fm_finish_w)"
+            empty["n0"] = "iteration 1 in chan (kh_chan2's launch), final sums in demod (kh_fm_demod2's launch)"
+        elif ND == 1024 and 2 * OLEN == ND and os.environ.get("KA9Q_HIP_N0_DIRECT", "-1") != "0":
+            empty["n0"] = "both iterations in fft2 (kh_fft_rows, direct mode), final sums in demod (kh_fm_demod2's launch)"
         for name, (ms, n) in st.items():
             if n:
                 avg = ms / n
@@ -632,7 +695,14 @@ def main():
             fft_ms = sum(stages[k]["ms"] for k in ("ingest", "fft1", "fft2") if k in stages)
             probe["recompute_forward_fft_ms"] = round(fft_ms, 4)
             if "broadcast_spectrum_ms" in probe:
-                probe["cheaper"] = "recompute per GPU" if fft_ms <= probe["broadcast_spectrum_ms"] else "spectrum broadcast"
+                # north_star: "whichever rocprof and RCCL timing show to be cheaper".  Options that replace the per-GPU
+                # transform: the full spectrum broadcast or the per-peer slices (option C); the input broadcast (option B)
+                # only replaces the host's fan-out and still needs the transform on every GPU.
+                cands = {"recompute per GPU": fft_ms, "spectrum broadcast": probe["broadcast_spectrum_ms"],
+                         "sliced spectrum (grouped send/recv)": probe.get("sliced_spectrum_ms", float("inf")),
+                         "input broadcast + recompute": probe["broadcast_input_ms"] + fft_ms}
+                probe["options_ms"] = {k: round(v, 4) for k, v in cands.items()}
+                probe["cheaper"] = min(cands, key=cands.get)
             out["exchange_probe"] = probe
         if world == 1 and not args.no_extra:
             out["shapes"] = shapes_leg(pyka9q, torch, device)

@@ -797,14 +797,13 @@ static bool n0_in_fft(const kh_bank *b) {
   return env && b->cfg.compute_n0 && b->N <= KH_MAX_SMALL_N;
 }
 // Four-step transforms: the row pass can take compute_n0's second iteration itself (N0Fuse, kh_internal.h), which
-// saves reading the spectrum a second time (8 N bytes per block) and costs ~5 us at the end of every row-pass launch
-// (the hand-over between the tiles of a block).  Measured (tools/shape_bench.py, us per step without / with):
-// N = 2^18, T = 32: 67.7 / 72.1 -- the re-read hides behind the latency-bound channel wavefronts there;
-// N = 2^19, T = 32: 183.5 / 172.2; N = 2^20, T = 16: 164.8 / 161.1.  Hence: from 2^19 on, unless KA9Q_HIP_N0_DIRECT says
-// 0 (never) or 1 (whenever possible).
+// saves reading the spectrum a second time (8 N bytes per block) and costs the row pass the rendezvous of a block's tiles
+// (N = 2^20, T = 16: 43.8 -> 58.2 us alone, profiles/r03_f1_*).  Round 2 took it from N = 2^19 on: at N = 2^18 the re-read
+// hid behind that round's latency-bound channel wavefronts.  With round 3's back half it does not any more (the re-read
+// is most of the channel stage, 24.5 -> 13.8 us at configs[1], and the step 76-80 -> 63 us), so: every four-step size,
+// unless KA9Q_HIP_N0_DIRECT says 0 (never) or 1 (whenever possible).
 static bool n0_direct(const kh_bank *b) {
   if (b->n0_direct_mode == 0 || !b->cfg.compute_n0 || b->N <= KH_MAX_SMALL_N) return false;
-  if (b->n0_direct_mode < 0 && b->N < (1 << 19)) return false;
   return n0_plan(b->N, b->cfg.samprate, b->cfg.n0_low, b->cfg.n0_high).valid != 0;
 }
 // BACK: compute_n0 (radio.c:422-465), per channel filter output (filter.c:240-384), demodulators, scaleclip.

@@ -9,7 +9,8 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-ORACLE_SO = os.path.join(_HERE, "libka9q_oracle.so")
+# KA9Q_ORACLE_SO: another build of the same source, e.g. the sanitizer build of `make -C oracle asan`
+ORACLE_SO = os.environ.get("KA9Q_ORACLE_SO") or os.path.join(_HERE, "libka9q_oracle.so")
 ORACLE_FAST_SO = os.path.join(_HERE, "libka9q_oracle_fast.so")
 REF_SO = os.path.join(_HERE, "_ref", "libka9q_ref.so")
 REF_PORTABLE_SO = os.path.join(_HERE, "_ref", "libka9q_ref_portable.so")
