@@ -72,7 +72,7 @@ struct kh_bank {
   int nslots = 3; // ring depth of what the front half hands to the back half (KA9Q_HIP_SLOTS, 2..4)
   int fused_ingest = 1;   // policy (KA9Q_HIP_FUSED_INGEST)
   int ride_n0 = 1;        // policy (KA9Q_HIP_RIDE_N0)
-  int n0_direct_mode = -1; // policy (KA9Q_HIP_N0_DIRECT): 0 never, 1 whenever possible, -1 (default) by transform size
+  int n0_direct_mode = -1; // policy (KA9Q_HIP_N0_DIRECT): 0 never, 1 rendezvous, 2 bracket, -1 (default) by transform size
   int n0_stagger = 0;      // KA9Q_HIP_N0_STAGGER (N0Fuse::stagger)
   int n0_spin = 1000;      // KA9Q_HIP_N0_SPIN: polls before a row-pass workgroup gives up (0: every block is re-read)
   bool fused_now = false; // this launch: large transform and no oscillator active
@@ -311,7 +311,7 @@ kh_bank *kh_bank_create(const struct kh_bank_config *cfg) {
   A(&b->d_istatus, P * T * sizeof(kh_input_status), true);
   for (int k = 0; k < b->nslots; k++) {
     A(&b->d_energy[k], P * T * std::max(ingest_chunks(cfg->L), fused_ingest_tiles(N)) * sizeof(float), true);
-    A(&b->d_n0acc[k], n0_part_floats() * P * T * sizeof(float), true);
+    A(&b->d_n0acc[k], (n0_part_floats() + (cfg->compute_n0 ? n0_cand_floats(N) : 0)) * P * T * sizeof(float), true);
   }
   A(&b->d_n0state, P * sizeof(float), false);
   A(&b->d_scalar, sizeof(float), true);
@@ -752,7 +752,7 @@ static int upload_channels(kh_bank *b) {
 // kh_bank_execute builds the hipGraphs of this shape.
 // FRONT: convert + mix (radio.c:136-191) and the forward transform (filter.c:212-238) into slot b->sp.
 static bool n0_in_fft(const kh_bank *b);
-static bool n0_direct(const kh_bank *b);
+static int n0_direct(const kh_bank *b);
 static int enqueue_front(kh_bank *b, hipStream_t st, unsigned int nblocks, bool prof) {
   int const L = b->cfg.L, M = b->cfg.M, N = b->N, P = b->P, sp = b->sp;
   size_t const need = (size_t)nblocks * L;
@@ -778,9 +778,11 @@ static int enqueue_front(kh_bank *b, hipStream_t st, unsigned int nblocks, bool 
   if (n0_on && (n0_in_fft(b) || n0_direct(b))) nf.part1 = b->d_n0acc[sp] + PT * N0_SLOTS;
   if (n0_on && n0_direct(b)) {
     nf.sync = reinterpret_cast<unsigned *>(b->d_n0acc[sp] + PT * (N0_SLOTS + 2 * N0_GX));
-    nf.direct = 1;
+    nf.direct = n0_direct(b);
     nf.spin = b->n0_spin;
     nf.stagger = b->n0_stagger;
+    nf.ewin = b->d_n0acc[sp] + PT * (N0_SLOTS + 2 * N0_GX); // (bracket mode: the same words, as floats)
+    nf.cand = b->d_n0acc[sp] + (size_t)n0_part_floats() * P * b->T;
   }
   if (launch_forward_fft(st, time, b->time_stride, 0, b->d_spec[sp], b->d_tmp, b->spec_stride, N, L, nblocks, P,
                          prof ? b->cur_ev[2] : nullptr, nf, fused ? &fi : nullptr))
@@ -802,9 +804,16 @@ static bool n0_in_fft(const kh_bank *b) {
 // hid behind that round's latency-bound channel wavefronts.  With round 3's back half it does not any more (the re-read
 // is most of the channel stage, 24.5 -> 13.8 us at configs[1], and the step 76-80 -> 63 us), so: every four-step size,
 // unless KA9Q_HIP_N0_DIRECT says 0 (never) or 1 (whenever possible).
-static bool n0_direct(const kh_bank *b) {
-  if (b->n0_direct_mode == 0 || !b->cfg.compute_n0 || b->N <= KH_MAX_SMALL_N) return false;
-  return n0_plan(b->N, b->cfg.samprate, b->cfg.n0_low, b->cfg.n0_high).valid != 0;
+// Since then there is bracket mode as well (2, kh_n0.cuh), which needs no rendezvous: the row pass loses 3 us (N = 2^18) to
+// 9 us (N = 2^20) less than with the rendezvous, and the channel stage carries the second step, 4 to 6 us.  Measured per
+// step, rendezvous / bracket: N = 2^18 63.7 / 65.9 us, 2^19 125-128 / 126-130, 2^20 (512 channels) 135-138 / 130-133,
+// (4096) 196-198 / 195.  So by default: the bracket from N = 2^20 on, the rendezvous below; KA9Q_HIP_N0_DIRECT = 1 / 2
+// selects one for every size, 0 neither.
+static int n0_direct(const kh_bank *b) {
+  if (b->n0_direct_mode == 0 || !b->cfg.compute_n0 || b->N <= KH_MAX_SMALL_N) return 0;
+  if (!n0_plan(b->N, b->cfg.samprate, b->cfg.n0_low, b->cfg.n0_high).valid) return 0;
+  if (b->n0_direct_mode == 1 || b->n0_direct_mode == 2) return b->n0_direct_mode;
+  return b->N >= (1 << 20) ? 2 : 1;
 }
 // BACK: compute_n0 (radio.c:422-465), per channel filter output (filter.c:240-384), demodulators, scaleclip.
 static int enqueue_back(kh_bank *b, hipStream_t st, unsigned int nblocks, bool prof) {
@@ -821,10 +830,11 @@ static int enqueue_back(kh_bank *b, hipStream_t st, unsigned int nblocks, bool p
   // blocks whose flag it raised; the iteration below then only runs for those)
   const unsigned *dsync = n0_direct(b) ? reinterpret_cast<const unsigned *>(b->d_n0acc[sp] + (size_t)P * nblocks * (N0_SLOTS + 2 * N0_GX))
                                        : nullptr;
+  const float *dcand = n0_direct(b) == 2 ? b->d_n0acc[sp] + (size_t)n0_part_floats() * P * b->T : nullptr;
   bool const ride = !in_fft && b->ride_n0 && chan_wave_supported(b->ND, b->olen) &&
-                    n0_pass1_args(&z, n0spec, b->spec_stride, N, plan, b->d_n0acc[sp], nblocks, P, dsync);
+                    n0_pass1_args(&z, n0spec, b->spec_stride, N, plan, b->d_n0acc[sp], nblocks, P, dsync, dcand);
   if (!ride && launch_n0(st, n0spec, b->spec_stride, N, b->cfg.samprate, plan, b->d_energy[sp], echunks, L, b->d_n0state,
-                         b->d_n0acc[sp], b->d_istatus, nblocks, P, in_fft ? 1 : 0, nullptr, dsync))
+                         b->d_n0acc[sp], b->d_istatus, nblocks, P, in_fft ? 1 : 0, nullptr, dsync, dcand))
     return -1;
   if (prof) hipEventRecord(b->cur_ev[4], st);
   int taken = 0;
@@ -846,7 +856,7 @@ static int enqueue_back(kh_bank *b, hipStream_t st, unsigned int nblocks, bool p
   N0FinalArgs nf;
   bool const ride_final = ride && taken && b->n_fm > 0 && (back2 || fm_finish_wave_usable(b->olen, nblocks));
   if (ride && launch_n0(st, n0spec, b->spec_stride, N, b->cfg.samprate, plan, b->d_energy[sp], echunks, L, b->d_n0state,
-                        b->d_n0acc[sp], b->d_istatus, nblocks, P, taken, ride_final ? &nf : nullptr, dsync))
+                        b->d_n0acc[sp], b->d_istatus, nblocks, P, taken, ride_final ? &nf : nullptr, dsync, dcand))
     return -1;
   if (prof) hipEventRecord(b->cur_ev[5], st);
   if (back2 && b->n_fm > 0 &&

@@ -280,6 +280,8 @@ __global__ __launch_bounds__(64 * C2_WAVES, OCC) void kh_chan2(Chan2Args A, N0Pa
     int const w = wg * C2_WAVES + wave;
     if (w < nwaves) chan2_wave<RB>(A, ex + wave * C2_WAVE_LDS, twl, w, threadIdx.x & 63);
   } else {
+    // (bracket mode's tasks were also tried inside the channel workgroups -- requested before the channel work, finished
+    // after it: the 40 registers they hold across it cost the 4096-channel bank 12 us and gained 2 us here)
     n0_pass1_body(Z, blockIdx.x - nchan_wg, reinterpret_cast<float *>(ex));
   }
 }

@@ -97,7 +97,7 @@ int launch_ingest(hipStream_t st, const void *raw, size_t raw_stride_bytes, int 
 // radio.c:197-202 block by block.
 // algorithmic bytes: 8*bincount
 __global__ __launch_bounds__(256) void kh_n0_pass1(N0Pass1Args Z) {
-  __shared__ float sh[8];
+  __shared__ float sh[16];
   n0_pass1_body(Z, blockIdx.x, sh);
 }
 
@@ -108,7 +108,7 @@ __global__ __launch_bounds__(N0_FT) void kh_n0_final(N0FinalArgs Z) {
 }
 
 // per (input, block): first-iteration partials | {sum, count} pairs of the second | direct mode's two words (N0Fuse)
-int n0_part_floats() { return N0_SLOTS + 2 * N0_GX + N0_SYNC_STRIDE; }
+int n0_part_floats() { return N0_SLOTS + 2 * N0_GX + N0_SYNC_STRIDE; } // (bracket mode's candidates: n0_cand_floats(N) more)
 
 N0Plan n0_plan(int N, int samprate, float low, float high) {
   N0Plan p{0, 0, 0};
@@ -131,14 +131,16 @@ N0Plan n0_plan(int N, int samprate, float low, float high) {
 // launch_chan_wave so that the iteration shares the channel kernel's launch, and then calls launch_n0 with
 // pass1_done = 1 for the rest.
 int n0_pass1_args(N0Pass1Args *z, const float2 *spec, size_t spec_in_stride, int N, N0Plan plan, float *part, int nblocks,
-                  int ninputs, const unsigned *sync) {
+                  int ninputs, const unsigned *sync, const float *cand) {
   if (spec == nullptr || !plan.valid) return 0;
-  *z = N0Pass1Args{spec, spec_in_stride, N, plan.start, plan.bincount, part, nblocks, ninputs, n0_partials(N), N0_GX, sync};
+  // (bracket mode: a workgroup per row tile; they sit at the end of the channel kernel's launch, so no more than needed)
+  *z = N0Pass1Args{spec, spec_in_stride, N, plan.start, plan.bincount, part, nblocks, ninputs, n0_partials(N),
+                   cand ? n0_partials(N) : N0_GX, sync, cand, n0_cols_tiles(N), n0_partials(N), n0_rows_waves(N)};
   return 1;
 }
 int launch_n0(hipStream_t st, const float2 *spec, size_t spec_in_stride, int N, int samprate, N0Plan plan,
               const float *energy_part, int echunks, int L, float *n0_state, float *part, void *input_status, int nblocks,
-              int ninputs, int pass1_done, N0FinalArgs *final_out, const unsigned *sync) {
+              int ninputs, int pass1_done, N0FinalArgs *final_out, const unsigned *sync, const float *cand) {
   if (nblocks <= 0 || ninputs <= 0) return 0;
   if (nblocks > N0_MAXB) {
     set_error("at most %d blocks per launch", N0_MAXB);
@@ -147,9 +149,9 @@ int launch_n0(hipStream_t st, const float2 *spec, size_t spec_in_stride, int N, 
   kh_input_status *status = static_cast<kh_input_status *>(input_status);
   int const have_n0 = spec != nullptr;
   N0Pass1Args z;
-  int const valid = n0_pass1_args(&z, spec, spec_in_stride, N, plan, part, nblocks, ninputs, sync);
+  int const valid = n0_pass1_args(&z, spec, spec_in_stride, N, plan, part, nblocks, ninputs, sync, cand);
   if (valid && !pass1_done)
-    hipLaunchKernelGGL(kh_n0_pass1, dim3(N0_GX * nblocks * ninputs), dim3(256), 0, st, z);
+    hipLaunchKernelGGL(kh_n0_pass1, dim3(z.gx * nblocks * ninputs), dim3(256), 0, st, z);
   N0FinalArgs const F{part, energy_part, echunks, L, N, samprate, valid, have_n0, n0_state, status, nblocks, ninputs};
   if (final_out) { // the caller lets it ride in the FM finish launch (launch_demod)
     *final_out = F;

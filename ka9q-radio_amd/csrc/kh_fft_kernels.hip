@@ -7,6 +7,7 @@
 //
 // Roofline: everything here streams; HBM bound.  No MFMA: nothing is a dense contraction.
 #include "kh_internal.h"
+#include "kh_n0.cuh"
 #include "kh_fft.cuh"
 #include "kh_regfft.cuh"
 #include "kh_anyfft.cuh"
@@ -283,7 +284,7 @@ template <int RA, int RB, int NT, bool INGEST>
 __global__ __launch_bounds__(NT, 4) void kh_fft_cols(const float2 *__restrict__ time, size_t in_stride,
                                                   float2 *__restrict__ tmp, size_t spec_in_stride, int N2, int L,
                                                   const float2 *__restrict__ tw, ColsTwiddle ct, ColsIngest ing, int b0,
-                                                  int nblocks, unsigned *__restrict__ n0sync) {
+                                                  int nblocks, unsigned *__restrict__ n0sync, float *__restrict__ ewin) {
   constexpr int W = TILE_W, R = RA * RB;
   constexpr int I1 = W * RB / NT; // RA-point transforms per lane
   constexpr int I2 = W * RA / NT; // RB-point transforms per lane
@@ -351,6 +352,15 @@ __global__ __launch_bounds__(NT, 4) void kh_fft_cols(const float2 *__restrict__ 
     }
     e = block_sum<NT>(e, red);
     if (tid == 0) ing.energy_part[((size_t)i * nblocks + b) * gridDim.x + tile] = e;
+  }
+  if (ewin != nullptr) { // uniform.  compute_n0, bracket mode (kh_n0.cuh): the energy of the block's N window samples
+    float e = 0.f;
+#pragma unroll
+    for (int u = 0; u < I1; u++)
+#pragma unroll
+      for (int a = 0; a < RA; a++) e += v[u][a].x * v[u][a].x + v[u][a].y * v[u][a].y;
+    e = block_sum<NT>(e, red);
+    if (tid == 0) ewin[N0_SYNC_STRIDE * ((size_t)i * nblocks + b) + tile] = e;
   }
 #pragma unroll
   for (int u = 0; u < I1; u++) {
@@ -438,7 +448,8 @@ __global__ __launch_bounds__(NT, 4) void kh_fft_cols(const float2 *__restrict__ 
 // the intermediate of the transform are re-read at once and fit the 256 MiB Infinity Cache only if the spectrum does not
 // push them out.  Measured: config 3's share 176 -> 157 us/step, config 4's 164 -> 152; nothing at configs[1], where
 // everything fits (nt on the raw loads, or sc0 / sc1 on these stores, measured worse).
-template <int RA, int RB, int NT, bool DIRECT, int SPEC_AUX>
+// MODE: compute_n0's second iteration: 0 not here, 1 direct (rendezvous of the block's tiles), 2 bracket (kh_n0.cuh)
+template <int RA, int RB, int NT, int MODE, int SPEC_AUX>
 __global__ __launch_bounds__(NT, 4) void kh_fft_rows(const float2 *__restrict__ tmp, float2 *__restrict__ spec,
                                                   size_t spec_in_stride, int N1, const float2 *__restrict__ tw,
                                                   N0Fuse n0, int b0, int nblocks) {
@@ -451,6 +462,7 @@ __global__ __launch_bounds__(NT, 4) void kh_fft_rows(const float2 *__restrict__ 
   __shared__ float red[NT / 64];
   __shared__ float th_sh;
   __shared__ int ok_sh, arrived_sh;
+  constexpr bool DIRECT = MODE == 1;
   if (DIRECT && threadIdx.x == 0) arrived_sh = 0; // (behind the exchange's barriers when it is used)
   int const tid = threadIdx.x;
   int const tile = blockIdx.x, bl = blockIdx.y, b = b0 + bl, i = blockIdx.z; // (b0, nblocks: as in kh_fft_cols)
@@ -458,6 +470,12 @@ __global__ __launch_bounds__(NT, 4) void kh_fft_rows(const float2 *__restrict__ 
   const float2 *src = tmp + i * spec_in_stride + (size_t)bl * N + (size_t)tile * W * R;
   if constexpr (DIRECT) { // (experiment, KA9Q_HIP_N0_STAGGER: see the rendezvous below)
     for (int k = (bl & 7) * n0.stagger; k > 0; k--) __builtin_amdgcn_s_sleep(8);
+  }
+  if constexpr (MODE == 2) { // the bracket's centre (read after the exchange's barriers)
+    if (tid < 64) {
+      float const t = n0_parseval_th(n0.ewin + N0_SYNC_STRIDE * ((size_t)i * nblocks + b), R / W, (int)N, n0.bincount);
+      if (tid == 0) th_sh = t;
+    }
   }
   float2 v[I1][RA];
 #pragma unroll
@@ -501,7 +519,7 @@ __global__ __launch_bounds__(NT, 4) void kh_fft_rows(const float2 *__restrict__ 
     for (int bb = 0; bb < RB; bb++) zi[u][bb] = ex[c * CS + w * RP + bb];
   }
   __amdgpu_buffer_rsrc_t const rout = make_rsrc(spec + i * spec_in_stride + (size_t)b * N + tile * W, (unsigned)N * 8u);
-  if constexpr (!DIRECT) {
+  if constexpr (MODE == 0) {
     float pw = 0.f;
 #pragma unroll
     for (int u = 0; u < I2; u++) {
@@ -522,6 +540,74 @@ __global__ __launch_bounds__(NT, 4) void kh_fft_rows(const float2 *__restrict__ 
       pw = block_sum<NT>(pw, red);
       if (tid == 0) n0.part[((size_t)i * nblocks + b) * N0_SLOTS + tile] = pw;
     }
+  } else if constexpr (MODE == 2) {
+    // ---- compute_n0, bracket mode (kh_n0.cuh): first-iteration sum per tile as above; below the bracket: sum and count
+    // per wavefront; inside it: the values themselves, per wavefront in lane order.  Nothing here waits for another tile.
+    static_assert(I2 == 1, "bracket mode keeps one row of outputs per lane");
+    int const w = tid % W, c = tid / W;
+    float2 z[RB];
+#pragma unroll
+    for (int bb = 0; bb < RB; bb++) z[bb] = make_float2(zr[0][bb], zi[0][bb]);
+    reg_fft<RB, -1>(z);
+    float const thP = th_sh, lo = thP * N0_BR_LO, hi = thP * N0_BR_HI;
+    float pw = 0.f, slo = 0.f, clo = 0.f;
+    int ncand = 0;
+    unsigned inside = 0; // bit d: output d is a candidate
+    static_assert(RB <= 32, "one bit per output");
+#pragma unroll
+    for (int d = 0; d < RB; d++) {
+      float const p = n0_power(z[d]);
+      bool const counts = n0_bin_counts(tile * W + w + N1 * (c + RA * d), (int)N, n0);
+      bool const below = counts && p < lo, cand = counts && !below && p < hi;
+      pw += counts ? p : 0.f;
+      slo += below ? p : 0.f;
+      clo += below ? 1.f : 0.f;
+      inside |= cand ? 1u << d : 0u;
+    }
+    ncand = __popc(inside);
+    // where this lane's candidates go: after those of the lanes before it
+    int off = ncand;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      int const t = __shfl_up(off, o, 64);
+      if ((tid & 63) >= o) off += t;
+    }
+    int const total = __shfl(off, 63, 64);
+    off -= ncand;
+    size_t const pt = (size_t)i * nblocks + b;
+    // candidates: staged in the wavefront's part of the exchange buffer (every wavefront has read its last value from it
+    // once the barrier below is passed), then written out 256 bytes at a time -- as 32 stores with two or three lanes
+    // each they cost more than the spectrum's own stores (N = 2^20: row pass 62 -> 79 us)
+    constexpr int NWV = NT / 64;
+    static_assert(RA * CS >= NWV * N0_CAPW, "the exchange buffer holds every wavefront's candidates");
+    int const K = gridDim.x * NWV, idx = tile * NWV + (tid >> 6);
+    float *hdr = n0.cand + pt * ((size_t)K * (N0_CAPW + 3)); // [3][K]: candidates found, sum and count below the bracket
+    float *region = hdr + 3 * (size_t)K + (size_t)idx * N0_CAPW;
+    float *stage = ex + (tid >> 6) * N0_CAPW;
+#pragma unroll
+    for (int d = 0; d < RB; d++) buf_store2<SPEC_AUX>(z[d], rout, (c * N1 + w) * 8, RA * d * N1 * 8); // X[k1 + N1*k2], k2 = c + RA*d
+    __syncthreads();
+#pragma unroll
+    for (int d = 0; d < RB; d++)
+      if (inside >> d & 1u) {
+        if (off < N0_CAPW) stage[off] = n0_power(z[d]);
+        off++;
+      }
+    // (a wavefront's LDS operations complete in order: no barrier between its own writes and reads)
+    int const nout = total < N0_CAPW ? total : N0_CAPW;
+    for (int k = tid & 63; k < nout; k += 64) region[k] = stage[k];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      slo += __shfl_xor(slo, o, 64);
+      clo += __shfl_xor(clo, o, 64);
+    }
+    if ((tid & 63) == 0) {
+      hdr[idx] = (float)total; // (above N0_CAPW: the block's second iteration re-reads the spectrum)
+      hdr[K + idx] = slo;
+      hdr[2 * K + idx] = clo;
+    }
+    pw = block_sum<NT>(pw, red);
+    if (tid == 0) n0.part[pt * N0_SLOTS + tile] = pw;
   } else {
   // ---- compute_n0, direct mode (N0Fuse)
   static_assert(I2 == 1, "direct mode keeps one row of outputs per lane");
@@ -617,7 +703,7 @@ static int launch_small(hipStream_t st, const void *time, size_t in_stride, int 
 
 template <int RA, int RB, int NT>
 static int launch_cols(hipStream_t st, const float2 *time, size_t in_stride, float2 *tmp, size_t spec_in_stride, int N2,
-                       int L, int nblocks, int ninputs, const FftIngest *fi, int b0, int gblocks, unsigned *n0sync) {
+                       int L, int nblocks, int ninputs, const FftIngest *fi, int b0, int gblocks, unsigned *n0sync, float *ewin) {
   const float2 *tw = twiddle_table(RA * RB);
   static_assert(RB % 16 == 0, "tq rows are read as float4");
   ColsTwiddle const ct = cols_twiddle(N2, RA, RB);
@@ -627,10 +713,10 @@ static int launch_cols(hipStream_t st, const float2 *time, size_t in_stride, flo
     ColsIngest const ing{static_cast<const unsigned char *>(fi->raw), fi->raw_stride_bytes, fi->raw_bytes, fi->payload,
                          fi->hist_in, fi->hist_out, fi->hist_stride, fi->desc, fi->energy_part, fi->M - 1};
     hipLaunchKernelGGL((kh_fft_cols<RA, RB, NT, true>), grid, dim3(NT), 0, st, time, in_stride, tmp, spec_in_stride, N2, L,
-                       tw, ct, ing, b0, nblocks, n0sync);
+                       tw, ct, ing, b0, nblocks, n0sync, ewin);
   } else {
     hipLaunchKernelGGL((kh_fft_cols<RA, RB, NT, false>), grid, dim3(NT), 0, st, time, in_stride, tmp, spec_in_stride, N2,
-                       L, tw, ct, ColsIngest{}, b0, nblocks, n0sync);
+                       L, tw, ct, ColsIngest{}, b0, nblocks, n0sync, ewin);
   }
   return KH_HIP(hipGetLastError()) ? 0 : -1;
 }
@@ -643,14 +729,21 @@ static int launch_rows(hipStream_t st, const float2 *tmp, float2 *spec, size_t s
   size_t const spec_bytes = (size_t)RA * RB * N1 * 8 * (size_t)nblocks * ninputs;            // of the whole call
   bool const nt = nt_env < 0 ? spec_bytes >= ((size_t)100 << 20) : nt_env != 0;
   dim3 const grid(N1 / TILE_W, gblocks, ninputs);
-  if (n0.direct && nt)
-    hipLaunchKernelGGL((kh_fft_rows<RA, RB, NT, true, 2>), grid, dim3(NT), 0, st, tmp, spec, spec_in_stride, N1, tw, n0, b0, nblocks);
-  else if (n0.direct)
-    hipLaunchKernelGGL((kh_fft_rows<RA, RB, NT, true, 0>), grid, dim3(NT), 0, st, tmp, spec, spec_in_stride, N1, tw, n0, b0, nblocks);
-  else if (nt)
-    hipLaunchKernelGGL((kh_fft_rows<RA, RB, NT, false, 2>), grid, dim3(NT), 0, st, tmp, spec, spec_in_stride, N1, tw, n0, b0, nblocks);
+  if constexpr (TILE_W * RA == NT) { // (one row of outputs per lane: the second iteration can stay in registers)
+    if (n0.direct == 2 && nt)
+      hipLaunchKernelGGL((kh_fft_rows<RA, RB, NT, 2, 2>), grid, dim3(NT), 0, st, tmp, spec, spec_in_stride, N1, tw, n0, b0, nblocks);
+    else if (n0.direct == 2)
+      hipLaunchKernelGGL((kh_fft_rows<RA, RB, NT, 2, 0>), grid, dim3(NT), 0, st, tmp, spec, spec_in_stride, N1, tw, n0, b0, nblocks);
+    else if (n0.direct && nt)
+      hipLaunchKernelGGL((kh_fft_rows<RA, RB, NT, 1, 2>), grid, dim3(NT), 0, st, tmp, spec, spec_in_stride, N1, tw, n0, b0, nblocks);
+    else if (n0.direct)
+      hipLaunchKernelGGL((kh_fft_rows<RA, RB, NT, 1, 0>), grid, dim3(NT), 0, st, tmp, spec, spec_in_stride, N1, tw, n0, b0, nblocks);
+    if (n0.direct) return KH_HIP(hipGetLastError()) ? 0 : -1;
+  }
+  if (nt)
+    hipLaunchKernelGGL((kh_fft_rows<RA, RB, NT, 0, 2>), grid, dim3(NT), 0, st, tmp, spec, spec_in_stride, N1, tw, n0, b0, nblocks);
   else
-    hipLaunchKernelGGL((kh_fft_rows<RA, RB, NT, false, 0>), grid, dim3(NT), 0, st, tmp, spec, spec_in_stride, N1, tw, n0, b0, nblocks);
+    hipLaunchKernelGGL((kh_fft_rows<RA, RB, NT, 0, 0>), grid, dim3(NT), 0, st, tmp, spec, spec_in_stride, N1, tw, n0, b0, nblocks);
   return KH_HIP(hipGetLastError()) ? 0 : -1;
 }
 
@@ -668,6 +761,14 @@ int n0_partials(int N) { // first-pass partial sums the forward transform leaves
   if (N <= KH_MAX_SMALL_N) return 1;
   return four_step_n1(N) / TILE_W; // one per row tile
 }
+
+int n0_cols_tiles(int N) { return N <= KH_MAX_SMALL_N ? 0 : (N / four_step_n1(N)) / TILE_W; }
+int n0_rows_waves(int N) { // (launch_rows' kernels: TILE_W x RA threads)
+  if (N <= KH_MAX_SMALL_N) return 0;
+  int const N2 = N / four_step_n1(N);
+  return N2 >= 1024 ? 8 : N2 >= 256 ? 4 : 2;
+}
+size_t n0_cand_floats(int N) { return N <= KH_MAX_SMALL_N ? 0 : (size_t)n0_partials(N) * n0_rows_waves(N) * (N0_CAPW + 3); }
 
 int fused_ingest_tiles(int N) { // IF power partial sums the fused column pass leaves per (input, block); 0: no fused pass
   if (N <= KH_MAX_SMALL_N) return 0;
@@ -741,16 +842,17 @@ int launch_forward_fft(hipStream_t st, const void *time, size_t in_stride, int r
   // back: a group's scratch is sized to stay in the 256 MiB Infinity Cache between the two, and every group of a call
   // reuses the same scratch, so most of that round trip never reaches HBM.
   int const group = fft_group_blocks(N, nblocks, ninputs);
-  unsigned *const n0sync = n0.direct ? n0.sync : nullptr;
+  unsigned *const n0sync = n0.direct == 1 ? n0.sync : nullptr;
+  float *const ewin = n0.direct == 2 ? n0.ewin : nullptr;
   int rc = 0;
   for (int b0 = 0; b0 < nblocks && !rc; b0 += group) {
     int const gb = nblocks - b0 < group ? nblocks - b0 : group;
     rc = -1;
     switch (N1) {
-    case 128: rc = launch_cols<8, 16, 128>(st, t, in_stride, tmp, spec_in_stride, N2, L, nblocks, ninputs, fi, b0, gb, n0sync); break;
-    case 256: rc = launch_cols<16, 16, 256>(st, t, in_stride, tmp, spec_in_stride, N2, L, nblocks, ninputs, fi, b0, gb, n0sync); break;
-    case 512: rc = launch_cols<16, 32, 256>(st, t, in_stride, tmp, spec_in_stride, N2, L, nblocks, ninputs, fi, b0, gb, n0sync); break;
-    case 1024: rc = launch_cols<32, 32, 512>(st, t, in_stride, tmp, spec_in_stride, N2, L, nblocks, ninputs, fi, b0, gb, n0sync); break;
+    case 128: rc = launch_cols<8, 16, 128>(st, t, in_stride, tmp, spec_in_stride, N2, L, nblocks, ninputs, fi, b0, gb, n0sync, ewin); break;
+    case 256: rc = launch_cols<16, 16, 256>(st, t, in_stride, tmp, spec_in_stride, N2, L, nblocks, ninputs, fi, b0, gb, n0sync, ewin); break;
+    case 512: rc = launch_cols<16, 32, 256>(st, t, in_stride, tmp, spec_in_stride, N2, L, nblocks, ninputs, fi, b0, gb, n0sync, ewin); break;
+    case 1024: rc = launch_cols<32, 32, 512>(st, t, in_stride, tmp, spec_in_stride, N2, L, nblocks, ninputs, fi, b0, gb, n0sync, ewin); break;
     }
     if (rc) return rc;
     if (mid_event && b0 == 0) hipEventRecord(mid_event, st);

@@ -149,6 +149,11 @@ struct N0Fuse {
   int direct = 0;
   int spin = 1000; // polls of ~0.1 us before a workgroup gives up (KA9Q_HIP_N0_SPIN; 0 sends every block to the re-read)
   int stagger = 0; // direct mode: a workgroup of block b starts (b mod 8) * stagger * ~0.25 us late (KA9Q_HIP_N0_STAGGER; see kh_fft_rows)
+  // N > KH_MAX_SMALL_N, bracket mode (direct == 2; kh_n0.cuh "bracket"): no workgroup waits for another.  The column pass
+  // leaves the energy of the block's N window samples (ewin: one partial per column tile in the block's N0_SYNC_STRIDE
+  // words), which bounds the threshold from above by Parseval; the row pass sums what lies below the bracket's lower
+  // edge and stores the few bins inside the bracket (cand); the exact threshold is applied to those when it is known.
+  float *ewin = nullptr, *cand = nullptr;
 };
 constexpr int N0_SYNC_STRIDE = 64; // 32-bit words per (input, block) in N0Fuse::sync: lines of its own
 int n0_partials(int N);
@@ -208,13 +213,17 @@ struct N0Plan {
 N0Plan n0_plan(int N, int samprate, float low, float high);
 // fills *z with the second iteration's arguments; 0 if there is nothing to do (compute_n0 off, empty bin range)
 // sync (may be null): direct mode's words (N0Fuse); the iteration then only runs for blocks whose flag is raised
+// cand (may be null): bracket mode's candidates; sync then holds the column pass's window energies
 int n0_pass1_args(N0Pass1Args *z, const float2 *spec, size_t spec_in_stride, int N, N0Plan plan, float *part, int nblocks,
-                  int ninputs, const unsigned *sync = nullptr);
+                  int ninputs, const unsigned *sync = nullptr, const float *cand = nullptr);
 // pass1_done: the second iteration has already run (inside launch_chan_wave's kernel)
 int launch_n0(hipStream_t st, const float2 *spec, size_t spec_in_stride, int N, int samprate, N0Plan plan,
               const float *energy_part, int echunks /*partial sums per (input, block)*/, int L, float *n0_state,
               float *part /*n0_part_floats() per (input,block)*/, void *input_status, int nblocks, int ninputs,
-              int pass1_done = 0, N0FinalArgs *final_out = nullptr, const unsigned *sync = nullptr);
+              int pass1_done = 0, N0FinalArgs *final_out = nullptr, const unsigned *sync = nullptr, const float *cand = nullptr);
+int n0_cols_tiles(int N);     // column tiles (= window energy partials) per block of a four-step transform
+int n0_rows_waves(int N);     // wavefronts per row tile
+size_t n0_cand_floats(int N); // bracket mode: candidate floats per (input, block); 0 for single-workgroup transforms
 // final_out != nullptr: kh_n0_final is not launched; *final_out receives its arguments for launch_demod
 // demodulators + scaleclip
 int launch_demod(hipStream_t st, float2 *baseband, size_t bb_stride, int olen, int nblocks, int nchan,

@@ -379,21 +379,29 @@ def test_full_ring_consumed_one_block_at_a_time(hip):
     single.close()
 
 
+@pytest.mark.parametrize("case", ["inband", "outband", "noise"])
 @pytest.mark.parametrize("shape", [(1_000_000, 8192, 8193, 32), (8_000_000, 131072, 131073, 256)])
-def test_compute_n0_modes_agree(hip, monkeypatch, shape):
-    """compute_n0's second iteration (radio.c:451-462) has three routes for a four-step transform: the spectrum is read a
+def test_compute_n0_modes_agree(hip, monkeypatch, shape, case):
+    """compute_n0's second iteration (radio.c:451-462) has these routes for a four-step transform: the spectrum is read a
     second time (KA9Q_HIP_N0_DIRECT=0); the row pass takes it from its registers once the tiles of a block have exchanged
-    their first-iteration sums (=1); and, when a tile's bounded wait for the others runs out, the block falls back to the
-    re-read (forced here with KA9Q_HIP_N0_SPIN=0).  All three must give the float64 evaluation of the same definition
-    to 1e-4 and each other to 1e-5, block after block (the smoothing of radio.c:199-202 carries across launches)."""
+    their first-iteration sums (=1), or, when a tile's bounded wait for the others runs out, the block falls back to the
+    re-read (forced here with KA9Q_HIP_N0_SPIN=0); and the bracket (=2, kh_n0.cuh): the row pass keeps the bins near an
+    upper bound of the threshold and the exact threshold is applied to those afterwards, unless the bound is off by more
+    than a quarter, which sends the block to the re-read.  The three inputs put the bracket through its paths: "inband"
+    has its strongest carrier inside the excluded range (three quarters of the power: the bound is far off), "outband" has
+    none there (the bound is tight, and the carriers lift the threshold far above the noise: no candidates), "noise" is
+    an empty band (a tenth of the bins are candidates, more than the slots requested in advance).  Every route must
+    give the float64 evaluation of the same definition to 1e-4 and the re-read's value to 1e-5, block after block (the
+    smoothing of radio.c:199-202 carries across launches)."""
     fs, L, M, D = shape
     N = L + M - 1
     T, calls = 3, 2
-    sigs = [(-2, 0.05, 400.0, 2500.0), (0, 0.2, 700.0, 2000.0), (3, 0.1, 1000.0, 3000.0)]  # channel 0 sits in the n0 passband
+    sigs = {"inband": [(-2, 0.05, 400.0, 2500.0), (0, 0.2, 700.0, 2000.0), (3, 0.1, 1000.0, 3000.0)],  # channel 0 sits in the n0 passband
+            "outband": [(-2, 0.05, 400.0, 2500.0), (3, 0.1, 1000.0, 3000.0)], "noise": []}[case]
     x = np.ascontiguousarray(synth.wideband_fm(11, T * calls * L, fs, N, sigs), np.complex64)
     results = {}
     for name, env in (("reread", {"KA9Q_HIP_N0_DIRECT": "0"}), ("direct", {"KA9Q_HIP_N0_DIRECT": "1"}),
-                      ("fallback", {"KA9Q_HIP_N0_DIRECT": "1", "KA9Q_HIP_N0_SPIN": "0"})):
+                      ("fallback", {"KA9Q_HIP_N0_DIRECT": "1", "KA9Q_HIP_N0_SPIN": "0"}), ("bracket", {"KA9Q_HIP_N0_DIRECT": "2"})):
         monkeypatch.delenv("KA9Q_HIP_N0_SPIN", raising=False)
         for k, v in env.items():
             monkeypatch.setenv(k, v)  # read by kh_bank_create
@@ -416,7 +424,7 @@ def test_compute_n0_modes_agree(hip, monkeypatch, shape):
     for name, n0s in results.items():
         for b, (g, r) in enumerate(zip(n0s, ref)):
             assert abs(g - r) <= 1e-4 * r, (name, b, g, r)
-    for name in ("direct", "fallback"):
+    for name in ("direct", "fallback", "bracket"):
         for b, (g, r) in enumerate(zip(results[name], results["reread"])):
             assert abs(g - r) <= 1e-5 * abs(r), (name, b, g, r)
 
