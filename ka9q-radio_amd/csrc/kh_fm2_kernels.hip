@@ -121,38 +121,67 @@ struct Fm2Chan { // what a block's group needs of its channel, in LDS
   float dsamprate, gain, lastaudio_in;
   float2 state_in;
 };
+// fm.c:73-78 asks one thing of the SNR: is it above 4.  fm_snr (fm.c:190-205) of r = avg^2/variance passes 4 at
+// r = 6.174478 (scanned over [pi/(4-pi), 100] in steps of 2.4e-5, and in steps of 5e-8 around the crossing; the stopping
+// rule makes it a sawtooth with teeth of at most 0.001): 3.971 at 6.15, 4.029 at 6.20, monotone outside up to those
+// teeth.  So the squelch of every block outside [6.15, 6.20] is known from r alone, without the iteration.
+constexpr float FM2_R_LO = 6.15f, FM2_R_HI = 6.20f;
+// all of a status record but .snr (the iteration's result: written by the lane that ran it)
+__device__ __forceinline__ void fm2_store_status(kh_status *p, kh_status const &r) {
+  float *w = reinterpret_cast<float *>(p);
+  static_assert(sizeof(kh_status) == 48 && offsetof(kh_status, snr) == 4, "word 1 is left to the SNR lane");
+  w[0] = r.bb_power;
+  *reinterpret_cast<float2 *>(w + 2) = make_float2(r.foffset, r.pdeviation);
+  *reinterpret_cast<float4 *>(w + 4) = make_float4(r.cphase, r.lock_timer, __int_as_float(r.pll_lock), r.output_level);
+  *reinterpret_cast<float4 *>(w + 8) = make_float4(r.agc_gain, __int_as_float(r.squelch_open), r.reserved[0], r.reserved[1]);
+}
 // A workgroup serves `cpw` FM channels (1, or up to 8 in a large bank); its items are their (channel, block) pairs, at most
-// 64.  It works in three steps:
-//   1. a lane per item: the block's statistics, fm_snr's iteration, the squelch; the open items go to a list in LDS.
-//      (The iteration costs a wavefront its slowest lane whatever the number of lanes in use, hence cpw > 1 in a large
-//      bank; with cpw == 1 a channel's blocks are dealt over all wavefronts instead, which shortens that wait.)
-//   2. the OPEN items, a group of G = olen/8 lanes each, as many per pass as the workgroup has groups: discriminator and
-//      de-emphasis from a zero carry, the block's carry-out to LDS, one barrier, then the carry-in's contribution (linear).
-//      A bank is mostly idle channels, so the groups of a workgroup go to the blocks that need them: one busy channel
-//      among idle ones gets every group (measured with time stamps per workgroup, 4096 channels x 16 blocks, one
-//      wavefront per channel: idle channels done after 15 us, the busy one after 34 us -- eight passes of its own).
-//   3. the closed items, a group each, no barrier: zeros (or the decaying carry, fm.c:124-132) and the status.
+// 64.  After one barrier (the items' statistics are in LDS) its wavefronts split into two roles that never wait for each
+// other:
+//   SNR wavefronts (the last four of a one-channel workgroup, one per SIMD; the last one otherwise): fm_snr's iteration, a
+//      lane per item, and the status word it yields.  0 .. 65 rounds of ~26 dependent fp64 instructions at a block's
+//      threshold, where idle channels sit: 7 to 15 us for the slowest lane, and a wavefront waits for its slowest lane.
+//   work wavefronts: the first of them, a lane per item: the squelch from r (above; the iteration only for an r inside
+//      [6.15, 6.20]), the list of OPEN items by ballot, and all there is to an idle item (closed, integrator at zero:
+//      nearly every item of a large bank): its status.  Then a group of G = olen/8 lanes per open item, taken from the list
+//      wherever they are -- one busy channel among idle ones gets every group: discriminator and de-emphasis from a zero
+//      carry, the block's carry-out to LDS with a "ready" bit; the carry-in's contribution (linear, fm.c:110-111) once the
+//      channel's earlier blocks are ready (they stand earlier in the list: whoever has them publishes before it waits, so
+//      the wait ends; it is bounded all the same).  Then the closed items that carry a decaying lastaudio (fm.c:124-132),
+//      then 16-byte zero stores for the idle ones.  An SNR wavefront that is done takes items as well.
+// A workgroup of one wavefront does the work first and iterates after it.
 template <int G>
-__global__ __launch_bounds__(1024) void kh_fm_demod2(Fm2Args F, int nfm_wg, N0FinalArgs Z, int n_fm, int cpw) {
+__global__ __launch_bounds__(1024) void kh_fm_demod2(Fm2Args F, int nfm_wg, N0FinalArgs Z, int n_fm, int cpw, float r_lo, float r_hi) {
   constexpr int K = 8, OLEN = K * G, PPW = 64 / G;
   static_assert(G == 32 || G == 64, "olen = 256 or 512");
   __shared__ double shB[FM2_MAXT]; // a block's integrator carry-out for a zero carry-in (0: closed)
   __shared__ __attribute__((aligned(16))) double sh_coef[KH_XI_SEGS * (KH_XI_DEG + 1)];
-  __shared__ float sh_snr[FM2_MAXT], sh_bbp[FM2_MAXT], sh_var[FM2_MAXT];
+  __shared__ float sh_r[FM2_MAXT], sh_bbp[FM2_MAXT], sh_var[FM2_MAXT];
   __shared__ unsigned char sh_list[FM2_MAXT]; // the open items in ascending order, then the closed ones
   __shared__ int sh_count[3];
+  __shared__ unsigned sh_gt4[2], sh_ready[2], sh_listed; // per item: SNR above 4; carry-out published; (flag) the list stands
+  __shared__ int sh_next[2];                              // tickets: the next entry of the list (open + decaying; idle)
   __shared__ Fm2Chan sh_ch[FM2_MAXCPW];
   if ((int)blockIdx.x >= nfm_wg) { // kh_n0_final's work (one workgroup per input) rides in this launch
-    n0_final_body(Z, blockIdx.x - nfm_wg, sh_snr, sh_bbp);
+    n0_final_body(Z, blockIdx.x - nfm_wg, sh_r, sh_bbp);
     return;
   }
   KH_T(0)
   int const lane64 = threadIdx.x & 63, wave = threadIdx.x >> 6, nwv = blockDim.x >> 6;
-  int const l = lane64 % G, gid = wave * PPW + lane64 / G, NG = nwv * PPW;
   int const par = F.par, nblocks = F.nblocks, items = cpw * nblocks; // items <= 64
   double const Ablk = F.decay_pow[OLEN];
+  // roles
+  int const nws = (cpw > 1 || nwv < 4) ? 1 : (nwv < 8 ? 2 : 4); // wavefronts that iterate: no more than half, one per SIMD
+  bool const split = nwv > nws;
+  int const nwork = split ? nwv - nws : nwv, ws = split ? wave - nwork : wave; // ws in [0, nws): iterates items ws, ws + nws, ..
+  bool const works = wave < nwork;
+  int const l = lane64 % G;
   double const dpl = F.decay_pow[K * l]; // decay^(K l)
-  // ---- step 1.  fm.c:53-70: statistics and the Rice-corrected SNR of every item
+  // ---- fm.c:53-70: the statistics kh_chan2 left, every item's by the lane that will iterate it
+  int const per = (ws >= 0 && ws < nws) ? (items + nws - 1) / nws : 0;
+  int const es = lane64 < per ? lane64 * nws + ws : items;
+  float r_it = 0.f; // fm_snr's argument avg^2 / variance
+  bool it_valid = false;
   {
     if ((int)threadIdx.x < cpw) {
       int const chi = threadIdx.x * nfm_wg + blockIdx.x; // neighbouring channels (busy together, if any are) go to different workgroups
@@ -168,70 +197,53 @@ __global__ __launch_bounds__(1024) void kh_fm_demod2(Fm2Args F, int nfm_wg, N0Fi
       sh_ch[threadIdx.x] = c;
     }
     for (int k = threadIdx.x; k < KH_XI_SEGS * (KH_XI_DEG + 1); k += blockDim.x) sh_coef[k] = (&kh_xi_coeffs[0][0])[k];
-    // Which wavefronts iterate.  A round is ~26 dependent vector instructions whatever the number of lanes in use, and the
-    // wavefronts that share a SIMD take turns (time stamps, 64 channels x 32 blocks dealt over 16 wavefronts, four to a SIMD:
-    // 270 ns a round; one wavefront per SIMD: ~60 ns).  So: cpw == 1: the first four wavefronts, one per SIMD, the items
-    // dealt round-robin (the blocks of idle channels sit at fm_snr's threshold, where the round count varies most, 0 .. 65:
-    // fewer lanes per wavefront shorten the wait for the slowest); cpw > 1: one wavefront, a different one in the
-    // workgroups that are likely to share a CU (they are dealt over 8 XCDs x 32 CUs).
-    int const nws = cpw > 1 ? 1 : (nwv < 4 ? nwv : 4), w0 = cpw > 1 ? (int)(blockIdx.x >> 8) % nwv : 0;
-    int const ws = wave - w0; // 0 .. nws-1: iterates
-    int const per = (ws >= 0 && ws < nws) ? (items + nws - 1) / nws : 0;
-    int const e = lane64 < per ? lane64 * nws + ws : items;
-    float r = 0.f; // kh_chan2 left avg^2 / variance in .snr
-    if (e < items) {
-      int const ce = e / nblocks, be = e - ce * nblocks, che = ce * nfm_wg + blockIdx.x;
+    if (threadIdx.x == 0) sh_listed = 0u, sh_next[0] = 0, sh_next[1] = 0;
+    if (es < items) {
+      int const ce = es / nblocks, be = es - ce * nblocks, che = ce * nfm_wg + blockIdx.x;
       if (che < n_fm) {
         const FmBlockStat *fs = F.stat + (size_t)F.list[che] * F.stat_stride + be;
         float const bbp = fs->bb_power, var = fs->variance;
-        r = fs->snr;
-        sh_bbp[e] = bbp, sh_var[e] = var;
+        r_it = fs->snr;
+        it_valid = true;
+        sh_bbp[es] = bbp, sh_var[es] = var, sh_r[es] = r_it;
       }
     }
-    __syncthreads();
+    __syncthreads(); // the only barrier
     KH_T(1)
-    if (lane64 < per) { // (spare lanes carry r = 0 and leave at once)
-      float const snr = fmaxf(0.0f, (float)fm_snr_lane((double)r, sh_coef));
-      if (e < items) sh_snr[e] = snr;
-    }
   }
-  __syncthreads();
+  // the iteration, and the status word it yields
+  auto iterate = [&]() {
+    if (lane64 < per) { // (spare lanes carry r = 0 and leave at once)
+      float const snr = fmaxf(0.0f, (float)fm_snr_lane((double)r_it, sh_coef));
+      if (it_valid) {
+        int const ce = es / nblocks, be = es - ce * nblocks;
+        F.status[(size_t)sh_ch[ce].ch * F.status_stride + be].snr = snr;
+      }
+    }
+  };
+  if (!works) iterate(); // (uniform per wavefront; afterwards these wavefronts take items like the others)
   // fm.c:73-78 in closed form (fm_counter_after, kh_demod_kernels.hip): the counter after block j is 1 if snr_j > 4, else
   // max(so_in - 1, 0) for j = 0 and 0 for j >= 1; a block demodulates iff snr > 4 or the counter before it is positive
-  auto squelch = [&](int e, int b, int so_in, bool &open, bool &open_p, int &so) {
-    float const snr_b = sh_snr[e];
-    float const snr_p = b >= 1 ? sh_snr[e - 1] : 0.f;
-    float const snr_pp = b >= 2 ? sh_snr[e - 2] : 0.f;
+  auto squelch = [&](unsigned long long g4, int e, int b, int so_in, bool &open, bool &open_p, int &so) {
+    bool const gt_b = g4 >> e & 1, gt_p = b >= 1 && (g4 >> (e - 1) & 1), gt_pp = b >= 2 && (g4 >> (e - 2) & 1);
     int const dec_in = so_in - 1 > 0 ? so_in - 1 : 0;
-    int const cnt_pp = b >= 2 ? (snr_pp > 4.f ? 1 : (b == 2 ? dec_in : 0)) : so_in; // counter before block b - 1
-    int const cnt_p = b >= 1 ? (snr_p > 4.f ? 1 : (b == 1 ? dec_in : 0)) : so_in;  // counter before block b
-    open = snr_b > 4.f || cnt_p > 0;
-    open_p = b >= 1 && (snr_p > 4.f || cnt_pp > 0);
-    so = snr_b > 4.f ? 1 : (b == 0 ? dec_in : 0);
+    int const cnt_pp = b >= 2 ? (gt_pp ? 1 : (b == 2 ? dec_in : 0)) : so_in; // counter before block b - 1
+    int const cnt_p = b >= 1 ? (gt_p ? 1 : (b == 1 ? dec_in : 0)) : so_in;  // counter before block b
+    open = gt_b || cnt_p > 0;
+    open_p = b >= 1 && (gt_p || cnt_pp > 0);
+    so = gt_b ? 1 : (b == 0 ? dec_in : 0);
   };
-  // the status of a block whose squelch is closed and whose audio is all zeros
-  auto idle_status = [&](int ch, int b, int e, int so) {
-    kh_status r;
-    r.bb_power = sh_bbp[e];
-    r.snr = sh_snr[e];
-    r.foffset = NAN; // fm.c:116,121 leave both untouched while the squelch is closed
-    r.pdeviation = NAN;
-    r.cphase = 0.f;
-    r.lock_timer = 0.f;
-    r.pll_lock = 0;
-    r.output_level = 0.f;
-    r.agc_gain = NAN;
-    r.squelch_open = so;
-    r.reserved[0] = r.reserved[1] = 0.f;
-    F.status[(size_t)ch * F.status_stride + b] = r;
-  };
-  if (wave == 0) {
+  if (wave == 0) { // (a work wavefront in either arrangement)
     int const e = lane64, ce = e / nblocks, b = e - ce * nblocks;
     bool const valid = e < items && ce * nfm_wg + (int)blockIdx.x < n_fm;
+    float const r = valid ? sh_r[e] : 0.f;
+    bool gt = r > r_hi; // (also r > 100, where fm_snr returns r)
+    if (valid && !gt && r >= r_lo) gt = fmaxf(0.0f, (float)fm_snr_lane((double)r, sh_coef)) > 4.f; // (~8 rounds there)
+    unsigned long long const g4 = __builtin_amdgcn_ballot_w64(valid && gt);
     bool open = false, open_p;
     int so = 0;
     Fm2Chan const C = sh_ch[ce < cpw ? ce : 0];
-    if (valid) squelch(e, b, C.so_in, open, open_p, so);
+    if (valid) squelch(g4, e, b, C.so_in, open, open_p, so);
     unsigned long long const mo = __builtin_amdgcn_ballot_w64(valid && open);
     // idle: closed, and the integrator holds 0 on entry (no open block of the channel before this one, lastaudio 0 from
     // the launch before; fma(A, 0, 0) = 0) or is not in use (flat).  All there is to such a block is its status here and
@@ -243,10 +255,23 @@ __global__ __launch_bounds__(1024) void kh_fm_demod2(Fm2Args F, int nfm_wg, N0Fi
     int const no = __popcll(mo), ng = __popcll(mg);
     if (valid)
       sh_list[open ? __popcll(mo & below) : !idle ? no + __popcll(mg & below) : no + ng + __popcll(mi & below)] = (unsigned char)e;
-    if (e == 0) sh_count[0] = no, sh_count[1] = no + ng, sh_count[2] = no + ng + __popcll(mi);
     shB[e] = 0.0;
+    if (e == 0) {
+      sh_count[0] = no, sh_count[1] = no + ng, sh_count[2] = no + ng + __popcll(mi);
+      sh_gt4[0] = (unsigned)g4, sh_gt4[1] = (unsigned)(g4 >> 32);
+      sh_ready[0] = ~(unsigned)mo, sh_ready[1] = ~(unsigned)(mo >> 32); // a closed block's carry-out is 0: ready
+    }
+    // (a wavefront's LDS operations complete in order: the flag follows everything above)
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    if (e == 0) __hip_atomic_store(&sh_listed, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     if (idle) {
-      idle_status(C.ch, b, e, so);
+      kh_status st_{};
+      st_.bb_power = sh_bbp[e];
+      st_.foffset = NAN; // fm.c:116,121 leave both untouched while the squelch is closed
+      st_.pdeviation = NAN;
+      st_.agc_gain = NAN;
+      st_.squelch_open = so;
+      fm2_store_status(F.status + (size_t)C.ch * F.status_stride + b, st_);
       if (b == nblocks - 1) { // state carried to the next launch (fm.c:26,32,33), into the other parity slot
         DemodState *st = F.states + C.ch;
         st->fm_lastaudio[par ^ 1] = C.flat ? C.lastaudio_in : 0.f;
@@ -255,31 +280,27 @@ __global__ __launch_bounds__(1024) void kh_fm_demod2(Fm2Args F, int nfm_wg, N0Fi
       }
     }
   }
-  __syncthreads();
+  // the other work wavefronts wait for the list (bounded: the first one is resident with them and waits for nothing)
+  for (int spin = 0; spin < (1 << 22) && !__hip_atomic_load(&sh_listed, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); spin++)
+    __builtin_amdgcn_s_sleep(1);
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
   KH_T(2)
   int const n_open = sh_count[0], n_gen = sh_count[1], n_all = sh_count[2];
-  for (int k = n_gen + gid; k < n_all; k += NG) { // fm.c:124-132 with lastaudio == 0: zeros, in either byte order
-    int const e = sh_list[k], ci = e / nblocks, b = e - ci * nblocks;
-    size_t const o = (size_t)sh_ch[ci].ch * F.pcm_stride + (size_t)b * OLEN + K * l;
-    *reinterpret_cast<uint4 *>(F.pcm + o) = make_uint4(0u, 0u, 0u, 0u);
-    if (F.audio) {
-      float4 *ao = reinterpret_cast<float4 *>(F.audio + o);
-      ao[0] = ao[1] = make_float4(0.f, 0.f, 0.f, 0.f);
-    }
-  }
-  // passes over the open items (uniform bounds: every thread meets every barrier), then the closed ones that carry a
-  // decaying lastaudio (a pass is all open items or all closed ones: the closed ones start at a pass of their own)
-  for (int p0 = 0; p0 < n_gen; p0 = (p0 < n_open && p0 + NG > n_open) ? n_open : p0 + NG) {
-    bool const open_pass = p0 < n_open;
-    int const k = p0 + gid;
-    bool const have = k < (open_pass ? n_open : n_gen);
-    int const e = have ? sh_list[k] : 0;
+  unsigned long long const g4 = (unsigned long long)sh_gt4[0] | ((unsigned long long)sh_gt4[1] << 32);
+  // the open items, then the closed ones that carry a decaying lastaudio: a group takes the next one of the list (in list
+  // order: what an item waits for was taken before it, by a group that publishes before it waits)
+  for (;;) {
+    int k = 0;
+    if (l == 0) k = __hip_atomic_fetch_add(&sh_next[0], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    k = __shfl(k, 0, G);
+    if (k >= n_gen) break;
+    int const e = sh_list[k];
     int const ci = e / nblocks, b = e - ci * nblocks;
     Fm2Chan const C = sh_ch[ci];
-    int const ch = C.ch < 0 ? 0 : C.ch, flat = C.flat;
-    bool open = false, open_p = false;
-    int so = 0;
-    if (have) squelch(e, b, C.so_in, open, open_p, so);
+    int const ch = C.ch, flat = C.flat;
+    bool open, open_p;
+    int so;
+    squelch(g4, e, b, C.so_in, open, open_p, so);
     const float2 *bbc = F.bb + (size_t)ch * F.bb_stride;
 
     float2 y[K];
@@ -341,13 +362,22 @@ __global__ __launch_bounds__(1024) void kh_fm_demod2(Fm2Args F, int nfm_wg, N0Fi
         if (l == 0) shB[e] = Bsum;
       }
     }
-    if (open_pass) __syncthreads(); // (uniform: p0 and n_open are)
-    if (open_pass && p0 == 0) { KH_T(4) }
-    if (!have) continue;
+    if (open && !flat) { // publish the carry-out
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+      if (l == 0) __hip_atomic_fetch_or(&sh_ready[e >> 5], 1u << (e & 31), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
     // lastaudio on entry to this block: the channel's blocks before it, each c <- decay^olen c + B (fm.c:110-111,130);
-    // the open ones among them stand earlier in the list, so their B is in LDS by now
+    // the open ones among them stand earlier in the list
     double c_in = (double)C.lastaudio_in;
     if (!flat) {
+      unsigned long long const need = (1ull << e) - (1ull << (e - b));
+      for (int spin = 0; spin < (1 << 22); spin++) {
+        unsigned long long const rd = (unsigned long long)__hip_atomic_load(&sh_ready[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) |
+                                      ((unsigned long long)__hip_atomic_load(&sh_ready[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) << 32);
+        if ((rd & need) == need) break;
+        __builtin_amdgcn_s_sleep(1);
+      }
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
       const double *Bc = shB + ci * nblocks;
       for (int j = 0; j < b; j++) c_in = fma(Ablk, c_in, Bc[j]);
     }
@@ -406,7 +436,6 @@ __global__ __launch_bounds__(1024) void kh_fm_demod2(Fm2Args F, int nfm_wg, N0Fi
       level = fm2_group_sum<G>(lv) / OLEN; // fm.c:135-138
     }
 
-    if (open_pass && p0 == 0) { KH_T(5) }
     // ---- fm.c:97-102, order dependent: pdev_pos is a running maximum; pdev_neg moves to ang_k at the first later
     // sample that is not a new maximum and whose lastaudio is below the current pdev_neg (see fm_finish_wave in
     // kh_demod_kernels.hip for the relaxation and why its fixed point is the serial result)
@@ -475,17 +504,12 @@ __global__ __launch_bounds__(1024) void kh_fm_demod2(Fm2Args F, int nfm_wg, N0Fi
         bool const changed = __float_as_int(ncin) != __float_as_int(cin);
         cin = ncin;
         if (!__builtin_amdgcn_ballot_w64(changed)) break;
-#ifdef KH_FM2_TIMES
-        if (threadIdx.x == 0 && blockIdx.x < 8192) kh_fm2_times[blockIdx.x * 8 + 7] = it;
-#endif
       }
       pdev_neg = last_val;
     }
-    if (open_pass && p0 == 0) { KH_T(6) }
     if (l == 0) {
-      kh_status r;
+      kh_status r{};
       r.bb_power = sh_bbp[e];
-      r.snr = sh_snr[e];
       r.foffset = NAN; // fm.c:116,121 leave both untouched while the squelch is closed
       r.pdeviation = NAN;
       if (open) {
@@ -495,14 +519,10 @@ __global__ __launch_bounds__(1024) void kh_fm_demod2(Fm2Args F, int nfm_wg, N0Fi
         pdev_neg -= avg_f;
         r.pdeviation = (float)((double)(C.dsamprate * fmaxf(pdev_pos, -pdev_neg)) * (0.5 * M_1_PI)); // fm.c:121
       }
-      r.cphase = 0.f;
-      r.lock_timer = 0.f;
-      r.pll_lock = 0;
       r.output_level = level;
       r.agc_gain = NAN;
       r.squelch_open = so;
-      r.reserved[0] = r.reserved[1] = 0.f;
-      F.status[(size_t)ch * F.status_stride + b] = r;
+      fm2_store_status(F.status + (size_t)ch * F.status_stride + b, r);
       if (b == nblocks - 1) { // state carried to the next launch (fm.c:26,32,33), into the other parity slot
         DemodState *st = F.states + ch;
         double c = c_in;
@@ -513,7 +533,21 @@ __global__ __launch_bounds__(1024) void kh_fm_demod2(Fm2Args F, int nfm_wg, N0Fi
       }
     }
   }
+  for (;;) { // the idle items: fm.c:124-132 with lastaudio == 0: zeros, in either byte order
+    int k = 0;
+    if (l == 0) k = __hip_atomic_fetch_add(&sh_next[1], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    k = n_gen + __shfl(k, 0, G);
+    if (k >= n_all) break;
+    int const e = sh_list[k], ci = e / nblocks, b = e - ci * nblocks;
+    size_t const o = (size_t)sh_ch[ci].ch * F.pcm_stride + (size_t)b * OLEN + K * l;
+    *reinterpret_cast<uint4 *>(F.pcm + o) = make_uint4(0u, 0u, 0u, 0u);
+    if (F.audio) {
+      float4 *ao = reinterpret_cast<float4 *>(F.audio + o);
+      ao[0] = ao[1] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  }
   KH_T(3)
+  if (!split) iterate(); // (too few wavefronts for two roles)
 }
 
 // KA9Q_HIP_BACK2=0: round 2's kernels (kh_back_a + kh_fm_finish_w), the A/B reference.  One path for every bank size on
@@ -542,24 +576,28 @@ int launch_fm2(hipStream_t st, const float2 *baseband, size_t bb_stride, int ole
                   pcm_big_endian, static_cast<kh_status *>(status), status_stride, fm_list};
   int const G = olen / 8, ppw = 64 / G;
   // Channels per workgroup: one, or in a large bank (>= 1024 FM channels) as many as fill a wavefront's lanes with items.
-  // Wavefronts: as many as keep every workgroup resident at once (5 wavefronts per SIMD, 5120 on the chip) -- a workgroup
-  // is a chain of dependent round trips, so a second round of workgroups doubles the stage -- and no more than give every
-  // item a group.
+  // Wavefronts: no more than give every item a group, and about as many as keep every workgroup resident at once (110
+  // VGPRs: 4 wavefronts per SIMD, 4096 on the chip).  Measured over the bench shapes (tools/micro/g8.sh): a quarter more
+  // than fit is still better -- idle channels' workgroups are gone after 6 us, and a busy channel with 32 open blocks
+  // needs groups more than it needs an early start (640 channels x 32 blocks: 4 wavefronts 45 us, 8: 31, 16: 42).
   static int const nw_env = getenv("KA9Q_HIP_FM2_WAVES") ? atoi(getenv("KA9Q_HIP_FM2_WAVES")) : 0;
   static int const cpw_env = getenv("KA9Q_HIP_FM2_CPW") ? atoi(getenv("KA9Q_HIP_FM2_CPW")) : 0;
   int cpw = cpw_env > 0 ? cpw_env : (n_fm >= 1024 ? FM2_MAXCPW : 1);
   if (cpw > FM2_MAXCPW) cpw = FM2_MAXCPW;
   while (cpw > 1 && cpw * nblocks > FM2_MAXT) cpw >>= 1;
   int const nwg = (n_fm + cpw - 1) / cpw;
-  int nw = 1; // a power of two: a workgroup's wavefronts then spread evenly over a CU's four SIMDs, and the last
-               // workgroups do not wait for a slot (1024 workgroups x 5 wavefronts: one in ten started 15 us late)
+  int nw = 1; // a power of two: a workgroup's wavefronts then spread evenly over a CU's four SIMDs
   while (nw < 16 && 2 * nw * nwg <= 5120 && nw * ppw < cpw * nblocks) nw *= 2;
   if (nw_env > 0) nw = nw_env > 16 ? 16 : nw_env;
+  // KA9Q_HIP_FM2_ITERATE_ALL=1 (test switch, read at every launch): the squelch of every block from the iteration, none from r alone
+  const char *const it_env = getenv("KA9Q_HIP_FM2_ITERATE_ALL");
+  int const it_all = it_env ? atoi(it_env) : 0;
+  float const r_lo = it_all ? 0.f : FM2_R_LO, r_hi = it_all ? INFINITY : FM2_R_HI;
   dim3 const grid(nwg + (n0final ? n0final->ninputs : 0));
   if (G == 32)
-    hipLaunchKernelGGL(kh_fm_demod2<32>, grid, dim3(64 * nw), 0, st, F, nwg, Z, n_fm, cpw);
+    hipLaunchKernelGGL(kh_fm_demod2<32>, grid, dim3(64 * nw), 0, st, F, nwg, Z, n_fm, cpw, r_lo, r_hi);
   else
-    hipLaunchKernelGGL(kh_fm_demod2<64>, grid, dim3(64 * nw), 0, st, F, nwg, Z, n_fm, cpw);
+    hipLaunchKernelGGL(kh_fm_demod2<64>, grid, dim3(64 * nw), 0, st, F, nwg, Z, n_fm, cpw, r_lo, r_hi);
   return KH_HIP(hipGetLastError()) ? 0 : -1;
 }
 

@@ -125,6 +125,44 @@ def test_fm_bank_8MSps(hip):
     assert all(abs(r[3]["pdeviation"] - 2500) < 150 for r in opened)
 
 
+def test_fm_squelch_from_r_alone_equals_the_iteration(hip, monkeypatch):
+    """kh_fm_demod2 decides a block's squelch (fm.c:73-78: is fm_snr above 4) from r = avg^2/variance alone when r is
+    outside [6.15, 6.20] -- fm_snr crosses 4 at r = 6.174478 -- and runs fm_snr's iteration before deciding only inside it;
+    the SNR itself is iterated by other wavefronts and only reported.  With KA9Q_HIP_FM2_ITERATE_ALL=1 every block's decision
+    comes from the iteration: PCM, audio and status of both runs must be identical bit for bit, over carriers whose SNR
+    ranges from far below to far above the threshold, and both must meet the oracle."""
+    fs, L, M, D = 8_000_000, 131072, 131073, 256
+    N = L + M - 1
+    # amplitudes around the squelch threshold (noise sigma 0.01 per component: 4 = 6 dB in a 11 kHz channel)
+    sigs = [(k - 8, a, 300.0 + 40 * k, 2500.0) for k, a in enumerate([0.0004, 0.0006, 0.0008, 0.001, 0.0012, 0.0014, 0.0016, 0.0018,
+                                                                       0.002, 0.0023, 0.0026, 0.003, 0.004, 0.006, 0.01, 0.05])]
+    T, calls = 4, 2
+    x = synth.wideband_fm(0, T * calls * L, fs, N, sigs)
+    runs = {}
+    for name, env in (("r", "0"), ("iterate", "1")):
+        monkeypatch.setenv("KA9Q_HIP_FM2_ITERATE_ALL", env)  # read at every launch
+        bank = hip.Bank(L, M, D, 1, len(sigs), T, fs)
+        for c, (k, _, _, _) in enumerate(sigs):
+            bank.set_channel(c, demod=hip.KH_DEMOD_FM, rotate=synth.rotate_for(k, 12500.0, N, fs), low=-5500.0, high=5500.0, kaiser_beta=3.0)
+        out = []
+        for call in range(calls):
+            bank.write_input(0, x[call * T * L:(call + 1) * T * L])
+            bank.execute(T)
+            out.append((np.stack([bank.pcm(c, T) for c in range(len(sigs))]),
+                        [bank.status(c, T) for c in range(len(sigs))]))
+        bank.close()
+        runs[name] = out
+    opened = 0
+    for (pa, sa), (pb, sb) in zip(runs["r"], runs["iterate"]):
+        assert np.array_equal(pa, pb)
+        for a, b in zip(sa, sb):
+            for f in ("snr", "squelch_open", "bb_power", "output_level"):
+                assert np.array_equal(np.asarray(a[f]), np.asarray(b[f])), f
+            opened += int(np.asarray(a["squelch_open"]).sum())
+    assert 0 < opened < len(sigs) * T * calls  # both sides of the threshold occur
+    _run_pair(hip, L, M, D, fs, sigs, x, T, calls)
+
+
 def test_fm_bank_ndec512_odd_block_counts(hip):
     """N_dec = 512 / olen = 256 (config 4's channel shape at a small N): two blocks of a channel share a wavefront in the
     channel kernel, so odd block counts leave a padding half; compute_n0 rides in the same launch."""
