@@ -580,8 +580,9 @@ int launch_fm2(hipStream_t st, const float2 *baseband, size_t bb_stride, int ole
   // VGPRs: 4 wavefronts per SIMD, 4096 on the chip).  Measured over the bench shapes (tools/micro/g8.sh): a quarter more
   // than fit is still better -- idle channels' workgroups are gone after 6 us, and a busy channel with 32 open blocks
   // needs groups more than it needs an early start (640 channels x 32 blocks: 4 wavefronts 45 us, 8: 31, 16: 42).
-  static int const nw_env = getenv("KA9Q_HIP_FM2_WAVES") ? atoi(getenv("KA9Q_HIP_FM2_WAVES")) : 0;
-  static int const cpw_env = getenv("KA9Q_HIP_FM2_CPW") ? atoi(getenv("KA9Q_HIP_FM2_CPW")) : 0;
+  // (KA9Q_HIP_FM2_WAVES, KA9Q_HIP_FM2_CPW: read at every launch -- the tests run one bank under several arrangements)
+  const char *const nw_s = getenv("KA9Q_HIP_FM2_WAVES"), *const cpw_s = getenv("KA9Q_HIP_FM2_CPW");
+  int const nw_env = nw_s ? atoi(nw_s) : 0, cpw_env = cpw_s ? atoi(cpw_s) : 0;
   int cpw = cpw_env > 0 ? cpw_env : (n_fm >= 1024 ? FM2_MAXCPW : 1);
   if (cpw > FM2_MAXCPW) cpw = FM2_MAXCPW;
   while (cpw > 1 && cpw * nblocks > FM2_MAXT) cpw >>= 1;

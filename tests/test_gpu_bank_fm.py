@@ -163,6 +163,49 @@ def test_fm_squelch_from_r_alone_equals_the_iteration(hip, monkeypatch):
     _run_pair(hip, L, M, D, fs, sigs, x, T, calls)
 
 
+@pytest.mark.parametrize("shape", [(8_000_000, 131072, 131073, 256, 5), (1_000_000, 8192, 8193, 32, 7)])
+def test_fm_demodulator_arrangements_are_bit_identical(hip, monkeypatch, shape):
+    """kh_fm_demod2 hands a workgroup 1 .. 8 channels (8 in banks of >= 1024 FM channels) and 1 .. 16 wavefronts, which
+    split into SNR and work wavefronts and take blocks by ticket.  None of that may show in the results: the same bank
+    run under forced arrangements (KA9Q_HIP_FM2_CPW x KA9Q_HIP_FM2_WAVES, including one wavefront that does everything,
+    channel counts that leave a workgroup partly empty, and more wavefronts than blocks) gives the same PCM, status and
+    carried state bit for bit over two launches; the default arrangement is held to the oracle by the tests around this
+    one.  13 channels: busy ones (squelch open throughout, opening late, closing), idle ones, a flat one."""
+    fs, L, M, D, T = shape
+    N = L + M - 1
+    calls = 2
+    nslots = int(fs / 2 / 12500.0) - 1
+    ks = [k for k in (-5, -4, -3, -2, -1, 0, 1, 2, 3, 4, 5, 6, 7) if abs(k) <= nslots]
+    amps = {-5: 0.05, -3: 0.0021, -2: 0.0024, 0: 0.1, 2: 0.0018, 3: 0.02, 6: 0.003}
+    sigs = [(k, amps[k], 300.0 + 35 * (k + 5), 2500.0) for k in ks if k in amps]
+    x = synth.wideband_fm(0, T * calls * L, fs, N, sigs)
+    x[: T * L // 2] *= 0.02  # the weaker carriers' squelches open during the first launch
+    results = {}
+    for cpw, waves in ((0, 0), (1, 1), (1, 2), (1, 16), (2, 1), (2, 3), (4, 4), (8, 1), (8, 16), (3, 5)):
+        monkeypatch.setenv("KA9Q_HIP_FM2_CPW", str(cpw))
+        monkeypatch.setenv("KA9Q_HIP_FM2_WAVES", str(waves))
+        bank = hip.Bank(L, M, D, 1, len(ks), T, fs)
+        for c, k in enumerate(ks):
+            bank.set_channel(c, demod=hip.KH_DEMOD_FM, rotate=synth.rotate_for(k, 12500.0, N, fs), low=-5500.0, high=5500.0,
+                             kaiser_beta=3.0, flat=int(k == 3))
+        out = []
+        for call in range(calls):
+            bank.write_input(0, x[call * T * L:(call + 1) * T * L])
+            bank.execute(T)
+            out.append(np.stack([bank.pcm(c, T) for c in range(len(ks))]))
+            for c in range(len(ks)):
+                st = bank.status(c, T)
+                out.append(np.concatenate([np.asarray(st[f], np.float64).ravel() for f in
+                                           ("bb_power", "snr", "foffset", "pdeviation", "output_level", "squelch_open")]))
+        bank.close()
+        results[(cpw, waves)] = out
+    ref = results[(0, 0)]
+    assert np.abs(ref[0]).max() > 500 and any(np.abs(r).max() == 0 for r in ref[0])  # open and squelched channels
+    for key, out in results.items():
+        for a, b in zip(ref, out):
+            assert np.array_equal(a, b, equal_nan=True), key
+
+
 def test_fm_bank_ndec512_odd_block_counts(hip):
     """N_dec = 512 / olen = 256 (config 4's channel shape at a small N): two blocks of a channel share a wavefront in the
     channel kernel, so odd block counts leave a padding half; compute_n0 rides in the same launch."""
