@@ -295,6 +295,8 @@ static void launch_chan2_rb(hipStream_t st, Chan2Args const &A, const N0Pass1Arg
   static int const occ = getenv("KA9Q_HIP_C2_OCC") ? atoi(getenv("KA9Q_HIP_C2_OCC")) : 1; // experiment: forced waves per SIMD
   if (occ == 4)
     hipLaunchKernelGGL((kh_chan2<RB, 4>), dim3(nchan_wg + extra), dim3(64 * C2_WAVES), 0, st, A, Z, nchan_wg, nwaves);
+  else if (occ == 3)
+    hipLaunchKernelGGL((kh_chan2<RB, 3>), dim3(nchan_wg + extra), dim3(64 * C2_WAVES), 0, st, A, Z, nchan_wg, nwaves);
   else
     hipLaunchKernelGGL((kh_chan2<RB, 1>), dim3(nchan_wg + extra), dim3(64 * C2_WAVES), 0, st, A, Z, nchan_wg, nwaves);
 }

@@ -1,0 +1,6 @@
+for o in 1 3; do
+echo "== C2_OCC=$o"
+for sh in "8000000 131072 131073 256 64 32" "8000000 131072 131073 256 640 32" "20000000 262144 262145 512 256 32" "20000000 262144 262145 512 1024 32" "64000000 524288 524289 2048 4096 16"; do
+KA9Q_HIP_C2_OCC=$o timeout -k 10 100 python3 tools/shape_bench.py $sh 2>/dev/null | grep "^FS=" | sed 's/FS=[0-9]* L=[0-9]* M=[0-9]* //' || exit 1
+done
+done
