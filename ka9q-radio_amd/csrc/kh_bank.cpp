@@ -805,10 +805,11 @@ static bool n0_in_fft(const kh_bank *b) {
 // is most of the channel stage, 24.5 -> 13.8 us at configs[1], and the step 76-80 -> 63 us), so: every four-step size,
 // unless KA9Q_HIP_N0_DIRECT says 0 (never) or 1 (whenever possible).
 // Since then there is bracket mode as well (2, kh_n0.cuh), which needs no rendezvous: the row pass loses 3 us (N = 2^18) to
-// 9 us (N = 2^20) less than with the rendezvous, and the channel stage carries the second step, 4 to 6 us.  Measured per
-// step, rendezvous / bracket: N = 2^18 63.7 / 65.9 us, 2^19 125-128 / 126-130, 2^20 (512 channels) 135-138 / 130-133,
-// (4096) 196-198 / 195.  So by default: the bracket from N = 2^20 on, the rendezvous below; KA9Q_HIP_N0_DIRECT = 1 / 2
-// selects one for every size, 0 neither.
+// 9 us (N = 2^20) less than with the rendezvous, and the channel stage carries the second step, 2 to 6 us.  Measured per
+// step, rendezvous / bracket (several runs each): bench.py (N = 2^18) 62.1-62.9 / 62.6-63.2 us; N = 2^19, 256 NBFM channels
+// 124-129 / 126-139, config 3's mixed share 191.6 / 191.6; N = 2^20 135-138 / 130-133 (512 channels), 196-198 / 190-195
+// (4096).  So by default: the bracket from N = 2^20 on, the rendezvous below; KA9Q_HIP_N0_DIRECT = 1 / 2 selects one for
+// every size (2: no workgroup ever waits for another, and which path a block takes depends on its data alone), 0 neither.
 static int n0_direct(const kh_bank *b) {
   if (b->n0_direct_mode == 0 || !b->cfg.compute_n0 || b->N <= KH_MAX_SMALL_N) return 0;
   if (!n0_plan(b->N, b->cfg.samprate, b->cfg.n0_low, b->cfg.n0_high).valid) return 0;

@@ -25,12 +25,21 @@ def rel_rms(a, b):
 RUNNING_SUM = []  # (what, field, relative difference): see check_state
 
 
-def check_state(got, ref, what, samples=0):
+def check_state(got, ref, what, samples=0, f64=None):
     for k, v in ref.items():
         g = got[k][0]
         if k in ("rotate_phase", "clips"):
             assert int(g) == v, f"{what}: {k} {g} vs {v}"
         elif abs(float(g) - v) > 1e-4 * abs(v) + 1e-7:
+            if samples >= 65536 and f64 is not None and k in f64() and abs(float(g) - v) > 3e-4 * abs(v) + 1e-7:
+                # beyond the allowance below: the estimator's state in float64 decides (the chain from transfer to transfer
+                # multiplies the running sums' error: three transfers of 131072 samples from imbalance 0 reached 4e-4).
+                # The GPU must be within 2e-5 of float64 and closer to it than the oracle is.
+                f = f64()[k]
+                assert abs(float(g) - f) <= 2e-5 * abs(f) + 1e-7 and abs(float(g) - f) <= abs(v - f), \
+                    f"{what}: {k} gpu {g} oracle {v} float64 {f}"
+                RUNNING_SUM.append((what, k, abs(float(g) - v) / abs(v)))
+                continue
             # hackrf.c:850-870 adds a transfer's I^2 and Q^2 into fp32 variables one sample at a time; from 65536 samples
             # on that running sum is itself ~1e-4 off (the device takes the sums from exact integer moments), and in_power
             # and the gains derived from it inherit that.  Allowed up to 3e-4 there, and reported.
@@ -79,7 +88,12 @@ def hackrf_rx_f64(iq, samples, nblocks, offset, rate, imb0):
             gq, gi = np.sqrt(0.5 * (1 + imbalance)), np.sqrt(0.5 * (1 + 1.0 / imbalance))
             sec = 1 / np.sqrt(1 - sinphi * sinphi)
             tan = sinphi * sec
+    F64_STATE.clear()
+    F64_STATE.update(dc_re=DC.real, dc_im=DC.imag, sinphi=sinphi, imbalance=imbalance, gain_i=gi, gain_q=gq, secphi=sec, tanphi=tan)
     return oi, oq
+
+
+F64_STATE = {}
 
 
 REFEREED = []
@@ -114,7 +128,10 @@ def hackrf_case(rng):
         eo = max(rel_rms(oi, fi.astype(np.float32)), rel_rms(oq, fq.astype(np.float32)))
         assert eg < 1e-5 and eg < eo, f"{what}: rails {e:.2e} (gpu-float64 {eg:.2e}, oracle-float64 {eo:.2e})"
         REFEREED.append(f"{what}: rails gpu-oracle {e:.2e}, gpu-float64 {eg:.2e}, oracle-float64 {eo:.2e}")
-    check_state(st_g, orc.fe_fields(st_o), what, samples)
+    def f64_state():
+        hackrf_rx_f64(iq, samples, nblocks, offset, rate, imb0)
+        return dict(F64_STATE)
+    check_state(st_g, orc.fe_fields(st_o), what, samples, f64_state)
     return what, e
 
 
