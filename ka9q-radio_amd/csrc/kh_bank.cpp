@@ -64,6 +64,10 @@ struct kh_bank {
   // front hands to the back is double buffered (sp = slot of the current launch), so the front of launch k+1 runs
   // beside the back of launch k.
   hipStream_t front = nullptr;
+  // mixed banks: the linear / AM demodulators run beside the FM demodulator (enqueue_back), on this stream
+  hipStream_t side = nullptr;
+  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+  int demod_fork = 1; // KA9Q_HIP_DEMOD_FORK=0: one after the other on the back stream
   static constexpr int MAX_SLOTS = 4;
   hipEvent_t ev_front_done[MAX_SLOTS] = {}, ev_back_done[MAX_SLOTS] = {};
   int sp = 0, last_sp = 0, pipeline = 1;
@@ -207,6 +211,9 @@ int kh_bank_destroy(kh_bank *b) {
     if (e) hipEventDestroy(e);
   for (auto &e : b->ev_back_done)
     if (e) hipEventDestroy(e);
+  if (b->ev_fork) hipEventDestroy(b->ev_fork);
+  if (b->ev_join) hipEventDestroy(b->ev_join);
+  if (b->side) hipStreamDestroy(b->side);
   if (b->front) hipStreamDestroy(b->front);
   if (b->stream) hipStreamDestroy(b->stream);
   delete b;
@@ -278,6 +285,10 @@ kh_bank *kh_bank_create(const struct kh_bank_config *cfg) {
     ok = ok && KH_HIP(hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking));
     ok = ok && KH_HIP(hipStreamCreateWithFlags(&b->front, hipStreamNonBlocking));
   }
+  ok = ok && (use_prio ? KH_HIP(hipStreamCreateWithPriority(&b->side, hipStreamNonBlocking, prio_hi))
+                       : KH_HIP(hipStreamCreateWithFlags(&b->side, hipStreamNonBlocking)));
+  ok = ok && KH_HIP(hipEventCreateWithFlags(&b->ev_fork, hipEventDisableTiming)) && KH_HIP(hipEventCreateWithFlags(&b->ev_join, hipEventDisableTiming));
+  if (const char *e = getenv("KA9Q_HIP_DEMOD_FORK")) b->demod_fork = atoi(e);
   unsigned const evflags = hipEventDisableTiming;
   for (auto &e : b->ev_front_done) ok = ok && KH_HIP(hipEventCreateWithFlags(&e, evflags));
   for (auto &e : b->ev_back_done) ok = ok && KH_HIP(hipEventCreateWithFlags(&e, evflags));
@@ -860,17 +871,28 @@ static int enqueue_back(kh_bank *b, hipStream_t st, unsigned int nblocks, bool p
                         b->d_n0acc[sp], b->d_istatus, nblocks, P, taken, ride_final ? &nf : nullptr, dsync, dcand))
     return -1;
   if (prof) hipEventRecord(b->cur_ev[5], st);
+  // A mixed bank's demodulators are independent kernels, each far from filling the chip (a workgroup per channel): the
+  // linear / AM ones go to a stream of their own beside the FM demodulator and join before the half ends (config 3's
+  // share, 128 NBFM + 64 AM + 64 USB: demod stage 94 us one after the other).
+  bool const fork = back2 && b->demod_fork && b->n_fm > 0 && b->n_lin + b->n_am > 0 && b->side != nullptr;
+  hipStream_t const sl = fork ? b->side : st;
+  if (fork) {
+    if (!KH_HIP(hipEventRecord(b->ev_fork, st)) || !KH_HIP(hipStreamWaitEvent(b->side, b->ev_fork, 0))) return -1;
+  }
   if (back2 && b->n_fm > 0 &&
       launch_fm2(st, b->d_bb, b->bb_stride, b->olen, nblocks, b->d_ddesc, b->d_dstate, b->keep_audio ? b->d_audio : nullptr, b->d_pcm,
                  b->pcm_stride, b->cfg.pcm_big_endian, b->d_status, b->T, b->d_lists, b->n_fm, b->d_fmstat, b->d_decaypow,
                  b->fm_parity, ride_final ? &nf : nullptr))
     return -1;
-  if (launch_demod(st, b->d_bb, b->bb_stride, b->olen, nblocks, C, b->d_ddesc, b->d_dstate,
+  if (launch_demod(sl, b->d_bb, b->bb_stride, b->olen, nblocks, C, b->d_ddesc, b->d_dstate,
                    b->keep_audio ? b->d_audio : nullptr, b->d_pcm, b->pcm_stride, b->cfg.pcm_big_endian, b->d_status,
                    b->T, b->d_lists, back2 ? 0 : b->n_fm, b->d_lists + C, b->n_lin, b->d_lists + 2 * C, b->n_am,
                    FmScratch{b->d_fmstat, b->d_fmwork, b->d_fmcarry, b->d_decaypow, b->fm_parity},
                    (ride_final && !back2) ? &nf : nullptr, b->n_lin_nopll))
     return -1;
+  if (fork) {
+    if (!KH_HIP(hipEventRecord(b->ev_join, b->side)) || !KH_HIP(hipStreamWaitEvent(st, b->ev_join, 0))) return -1;
+  }
   if (b->rtp && launch_rtp_plan(st, b->d_pcm, b->pcm_stride, b->olen, nblocks, C, b->d_ddesc, b->d_rtp, b->rtp_stride,
                                 b->d_rtpstate))
     return -1;
