@@ -46,4 +46,23 @@ for _ in range(steps):
 bank.sync()
 dt = (time.perf_counter() - t0) / steps
 print(f"PLAN={key} channels={len(plan)} blocks={nb}: {dt*1e6:.1f} us/step")
+if os.environ.get("PLAN_STAGES"):  # per-stage HIP events, every kernel alone (one stream)
+    bank.profile(1)
+    for _ in range(5):
+        step()
+    bank.sync()
+    print("stages alone (us):", {k: round(1e3 * ms / n, 1) for k, (ms, n) in bank.stage_times().items() if n})
+if hasattr(pyka9q.lib(), "kh_debug_fm2_times"):  # a -DKH_FM2_TIMES build (tools/micro/build_dbg.sh): where kh_fm_demod2's workgroups spend their time
+    import ctypes as C, numpy as np
+    L_ = pyka9q.lib()
+    n = 8192
+    buf = np.zeros(n * 8, dtype=np.int64)
+    L_.kh_debug_fm2_times.argtypes = [C.c_void_p, C.c_int]
+    if L_.kh_debug_fm2_times(buf.ctypes.data, n * 8) == 0:
+        tt = buf.reshape(n, 8).astype(np.float64) / 100.0
+        tt = tt[tt[:, 3] > 0]
+        t0_ = tt[:, 0].min()
+        print("kh_fm_demod2 workgroups", len(tt), "span us", round(tt[:, 3].max() - t0_, 2))
+        for name, v in (("loads", tt[:, 1] - tt[:, 0]), ("to list", tt[:, 2] - tt[:, 1]), ("items", tt[:, 3] - tt[:, 2]), ("life", tt[:, 3] - tt[:, 0])):
+            print(f"  {name:10s} min {v.min():7.2f} p50 {np.median(v):7.2f} p90 {np.percentile(v, 90):7.2f} max {v.max():7.2f}")
 bank.close()
