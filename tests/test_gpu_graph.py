@@ -15,14 +15,22 @@ N = L + M - 1
 LAUNCHES = [2, 2, 2, 2, 2, 2, 2, 3, 3, 3, 3, 3, 3, 3, 2, 2, 1, 1, 1, 1, 1, 1]  # the block count changes in the middle, twice
 
 
-def _banks(hip, n, payload):
+def _banks(hip, n, payload, mixed=False):
+    """mixed: the last two channels are USB with hang AGC and envelope AM -- a bank whose linear demodulators run on a
+    stream of their own beside the FM demodulator (a fork and a join inside the captured back half)"""
     sigs = [(k - 3, 0.03 + 0.01 * k, 300.0 + 60 * k, 2500.0) for k in range(C)]
+    out_rate = FS / D
     out = []
     for _ in range(n):
         b = hip.Bank(L, M, D, 1, C, T, FS, payload=payload, compute_n0=1, n0_low=-5500.0, n0_high=5500.0)
         for c, (k, *_r) in enumerate(sigs):
-            b.set_channel(c, demod=hip.KH_DEMOD_FM, rotate=synth.rotate_for(k, 12500.0, N, FS), low=-5500.0, high=5500.0,
-                          kaiser_beta=3.0)
+            rot = synth.rotate_for(k, 12500.0, N, FS)
+            if mixed and c >= C - 2:
+                b.set_channel(c, demod=hip.KH_DEMOD_LINEAR, rotate=rot, low=100.0 if c == C - 2 else -5000.0, high=3000.0 if c == C - 2 else 5000.0,
+                              kaiser_beta=3.0, pll=0, agc=1, env=int(c == C - 1), hangtime=1.1 * out_rate,
+                              recovery_rate=10 ** ((6.0 / out_rate) / 20), agc_gain=1e3)
+            else:
+                b.set_channel(c, demod=hip.KH_DEMOD_FM, rotate=rot, low=-5500.0, high=5500.0, kaiser_beta=3.0)
         out.append(b)
     return sigs, out
 
@@ -39,8 +47,9 @@ def _snapshot(b, nb):
     return (b.pcm_all(nb).copy(), b.input_status(0, nb).tobytes(), [b.status(c, nb).tobytes() for c in range(C)])
 
 
-def test_graph_replay_matches_plain_launches_write_input(hip):
-    sigs, (plain, graph) = _banks(hip, 2, hip.KH_PT_IQ16LE)
+@pytest.mark.parametrize("mixed", [False, True])
+def test_graph_replay_matches_plain_launches_write_input(hip, mixed):
+    sigs, (plain, graph) = _banks(hip, 2, hip.KH_PT_IQ16LE, mixed)
     raw = _raw(hip, sigs)
     graph.use_graph(1)
     pos = 0
@@ -92,3 +101,26 @@ def test_graph_replay_matches_plain_launches_stream(hip):
     for b in (plain, graph):
         b.stream_close()
         b.close()
+
+
+def test_mixed_bank_demodulators_side_by_side_or_in_sequence(hip, monkeypatch):
+    """a mixed bank runs its linear / AM demodulators on a third stream beside the FM demodulator (KA9Q_HIP_DEMOD_FORK=0:
+    one after the other on the back stream): the same bits either way, launch after launch without a host sync between"""
+    raw = None
+    snaps = []
+    for fork in ("1", "0"):
+        monkeypatch.setenv("KA9Q_HIP_DEMOD_FORK", fork)  # read by kh_bank_create
+        sigs, (b,) = _banks(hip, 1, hip.KH_PT_IQ16LE, mixed=True)
+        if raw is None:
+            raw = _raw(hip, sigs)
+        pos, out = 0, []
+        for nb in LAUNCHES[:10]:
+            b.write_input(0, raw[2 * pos:2 * (pos + nb * L)], count=nb * L)
+            b.execute(nb, sync=False)
+            out.append(_snapshot(b, nb))
+            pos += nb * L
+        b.close()
+        snaps.append(out)
+    for j, (a, c) in enumerate(zip(*snaps)):
+        assert np.array_equal(a[0], c[0]) and a[1] == c[1] and a[2] == c[2], j
+    assert np.abs(snaps[0][-1][0][C - 2:]).max() > 100  # the linear channels produce audio
