@@ -65,7 +65,9 @@ struct kh_bank {
   // beside the back of launch k.
   hipStream_t front = nullptr;
   // mixed banks: the linear / AM demodulators run beside the FM demodulator (enqueue_back), on this stream
-  hipStream_t side = nullptr;
+  hipStream_t side = nullptr; // created with the first launch that forks (a bank that never does has no third stream)
+  int side_prio = 0;
+  bool side_use_prio = false;
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   int demod_fork = 1; // KA9Q_HIP_DEMOD_FORK=0: one after the other on the back stream
   static constexpr int MAX_SLOTS = 4;
@@ -285,9 +287,8 @@ kh_bank *kh_bank_create(const struct kh_bank_config *cfg) {
     ok = ok && KH_HIP(hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking));
     ok = ok && KH_HIP(hipStreamCreateWithFlags(&b->front, hipStreamNonBlocking));
   }
-  ok = ok && (use_prio ? KH_HIP(hipStreamCreateWithPriority(&b->side, hipStreamNonBlocking, prio_hi))
-                       : KH_HIP(hipStreamCreateWithFlags(&b->side, hipStreamNonBlocking)));
-  ok = ok && KH_HIP(hipEventCreateWithFlags(&b->ev_fork, hipEventDisableTiming)) && KH_HIP(hipEventCreateWithFlags(&b->ev_join, hipEventDisableTiming));
+  b->side_prio = use_prio ? prio_hi : 0;
+  b->side_use_prio = use_prio;
   if (const char *e = getenv("KA9Q_HIP_DEMOD_FORK")) b->demod_fork = atoi(e);
   unsigned const evflags = hipEventDisableTiming;
   for (auto &e : b->ev_front_done) ok = ok && KH_HIP(hipEventCreateWithFlags(&e, evflags));
@@ -874,7 +875,18 @@ static int enqueue_back(kh_bank *b, hipStream_t st, unsigned int nblocks, bool p
   // A mixed bank's demodulators are independent kernels, each far from filling the chip (a workgroup per channel): the
   // linear / AM ones go to a stream of their own beside the FM demodulator and join before the half ends (config 3's
   // share, 128 NBFM + 64 AM + 64 USB: demod stage 94 us one after the other).
-  bool const fork = back2 && b->demod_fork && b->n_fm > 0 && b->n_lin + b->n_am > 0 && b->side != nullptr;
+  // Not under hipGraph capture: the runtime picks the streams of a replayed graph's branches itself, and two branches that
+  // land on one hardware queue with the join ahead of the side branch's kernels never finish (one full-suite run of the
+  // graph tests with the fork inside the captured half timed out in kh_bank_sync).  Plain launches reach the queues in the
+  // order below -- everything the join waits for is queued ahead of it -- whatever the mapping of streams to queues.
+  bool fork = back2 && b->demod_fork && !b->use_graph && b->n_fm > 0 && b->n_lin + b->n_am > 0;
+  if (fork && b->side == nullptr) {
+    bool ok = b->side_use_prio ? KH_HIP(hipStreamCreateWithPriority(&b->side, hipStreamNonBlocking, b->side_prio))
+                               : KH_HIP(hipStreamCreateWithFlags(&b->side, hipStreamNonBlocking));
+    ok = ok && KH_HIP(hipEventCreateWithFlags(&b->ev_fork, hipEventDisableTiming)) &&
+         KH_HIP(hipEventCreateWithFlags(&b->ev_join, hipEventDisableTiming));
+    if (!ok) fork = false;
+  }
   hipStream_t const sl = fork ? b->side : st;
   if (fork) {
     if (!KH_HIP(hipEventRecord(b->ev_fork, st)) || !KH_HIP(hipStreamWaitEvent(b->side, b->ev_fork, 0))) return -1;

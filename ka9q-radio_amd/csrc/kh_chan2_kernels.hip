@@ -73,7 +73,7 @@ constexpr int C2_WAVE_LDS = 1152;
 // edge.  When no pair of the wavefront wraps (FAST), the 31 regular loads are one base address and immediate offsets.
 // rp: response + l, in global memory or in LDS (the two calls are separate so that each keeps its address space).
 template <int RB, bool FAST>
-__device__ __forceinline__ void c2_products(float2 (&v)[C2_RA], const float2 *__restrict__ rp, const float2 *__restrict__ fd, int m0,
+__device__ __forceinline__ void c2_products(v2f (&v)[C2_RA], const float2 *__restrict__ rp, const float2 *__restrict__ fd, int m0,
                                             int l, int N) {
   constexpr int ND = C2_RA * RB, H = ND / 2 + 1;
   if constexpr (FAST) {
@@ -81,10 +81,10 @@ __device__ __forceinline__ void c2_products(float2 (&v)[C2_RA], const float2 *__
 #pragma unroll
     for (int a = 0; a < C2_RA; a++) {
       if (a == 16) {
-        v[a] = cmul(rp[RB * a], fd[m0 + ((l - 1) & (ND - 1))]);
+        v[a] = pk::cmul(pk::load(rp[RB * a]), pk::load(fd[m0 + ((l - 1) & (ND - 1))]));
       } else {
         int const off = RB * a + (a < 16 ? ND - H : -H); // >= 0
-        v[a] = cmul(rp[RB * a], fl[off]);
+        v[a] = pk::cmul(pk::load(rp[RB * a]), pk::load(fl[off]));
       }
     }
   } else {
@@ -93,7 +93,7 @@ __device__ __forceinline__ void c2_products(float2 (&v)[C2_RA], const float2 *__
       int const i = (RB * a + l - H) & (ND - 1);
       int m = m0 + i;
       if (m >= N) m -= N;
-      v[a] = cmul(rp[RB * a], fd[m]);
+      v[a] = pk::cmul(pk::load(rp[RB * a]), pk::load(fd[m]));
     }
   }
 }
@@ -124,7 +124,7 @@ __device__ __forceinline__ void chan2_wave(Chan2Args const &A, float2 *exw, cons
   if (m0 >= N) m0 -= N;
   if (m0 < 0) m0 += N;
   bool const fast = __builtin_amdgcn_ballot_w64(m0 + ND > N) == 0;
-  float2 v[RA];
+  v2f v[RA]; // (packed pairs: kh_regfft.cuh)
   if (one_channel) {
     const float2 *rc = A.response + (size_t)ch * ND + lane64;
 #pragma unroll
@@ -153,70 +153,71 @@ __device__ __forceinline__ void chan2_wave(Chan2Args const &A, float2 *exw, cons
           int m = m0 + i;
           if (m >= N) m -= N;
           float2 const o = cmul(A.response[(size_t)ch * ND + dn], fd[m]);
-          v[a] = p < ND / 2 ? cadd(v[a], cconj(o)) : csub(v[a], cconj(o));
+          float2 const va = pk::store(v[a]);
+          v[a] = pk::load(p < ND / 2 ? cadd(va, cconj(o)) : csub(va, cconj(o)));
         }
       }
     }
   }
 
   // ---- stage A
-  reg_fft<RA, +1>(v);
+  pk::reg_fft<RA, +1>(v);
   {
     const float2 *tw = twl + l;
 #pragma unroll
-    for (int c = 1; c < RA; c++) v[c] = cmul(v[c], tw[c * RB]);
+    for (int c = 1; c < RA; c++) v[c] = pk::cmul(v[c], pk::load(tw[c * RB]));
   }
 
   // ---- exchange + stage B
   float2 y[16]; // sample l + RB m of the block (filter.c:197,206: the last OLEN points)
   if constexpr (RB == 32) {
-    float2 u[32];
+    v2f u[32];
 #pragma unroll
     for (int h = 0; h < 2; h++) {
 #pragma unroll
-      for (int c = 0; c < 16; c++) ex[c * PITCH + l] = v[16 * h + c];
+      for (int c = 0; c < 16; c++) ex[c * PITCH + l] = pk::store(v[16 * h + c]);
       c2_wave_sync();
       if ((l >> 4) == h) {
         const float4 *row = reinterpret_cast<const float4 *>(ex + (l & 15) * PITCH);
 #pragma unroll
         for (int j = 0; j < 16; j++) {
           float4 const t = row[j];
-          u[2 * j] = make_float2(t.x, t.y);
-          u[2 * j + 1] = make_float2(t.z, t.w);
+          u[2 * j] = (v2f){t.x, t.y};
+          u[2 * j + 1] = (v2f){t.z, t.w};
         }
       }
       c2_wave_sync();
     }
-    reg_fft<32, +1>(u); // X[l + 32 d]; d >= 16 is the block's output (the unused half is dead code to the compiler)
+    pk::reg_fft<32, +1>(u); // X[l + 32 d]; d >= 16 is the block's output (the unused half is dead code to the compiler)
 #pragma unroll
-    for (int m = 0; m < 16; m++) y[m] = u[16 + m];
+    for (int m = 0; m < 16; m++) y[m] = pk::store(u[16 + m]);
   } else {
-    float2 u0[16], u1[16];
+    v2f u0[16], u1[16];
 #pragma unroll
     for (int h = 0; h < 2; h++) {
 #pragma unroll
-      for (int c = 0; c < 16; c++) ex[c * PITCH + l] = v[16 * h + c];
+      for (int c = 0; c < 16; c++) ex[c * PITCH + l] = pk::store(v[16 * h + c]);
       c2_wave_sync();
       const float4 *row = reinterpret_cast<const float4 *>(ex + l * PITCH);
 #pragma unroll
       for (int j = 0; j < 8; j++) {
         float4 const t = row[j];
         if (h == 0) {
-          u0[2 * j] = make_float2(t.x, t.y);
-          u0[2 * j + 1] = make_float2(t.z, t.w);
+          u0[2 * j] = (v2f){t.x, t.y};
+          u0[2 * j + 1] = (v2f){t.z, t.w};
         } else {
-          u1[2 * j] = make_float2(t.x, t.y);
-          u1[2 * j + 1] = make_float2(t.z, t.w);
+          u1[2 * j] = (v2f){t.x, t.y};
+          u1[2 * j + 1] = (v2f){t.z, t.w};
         }
       }
       c2_wave_sync();
     }
-    reg_fft<16, +1>(u0); // X[l + 32 d]
-    reg_fft<16, +1>(u1); // X[l + 16 + 32 d]
+    pk::reg_fft<16, +1>(u0); // X[l + 32 d]
+    pk::reg_fft<16, +1>(u1); // X[l + 16 + 32 d]
 #pragma unroll
     for (int e = 0; e < 8; e++) {
-      y[2 * e] = u0[8 + e];
-      y[2 * e + 1] = u1[8 + e];
+      y[2 * e] = pk::store(u0[8 + e]);
+      y[2 * e + 1] = pk::store(u1[8 + e]);
     }
   }
 

@@ -96,4 +96,71 @@ __host__ __device__ __forceinline__ void reg_fft(float2 (&v)[N]) {
   }
 }
 
+// ---- the same transforms on packed pairs: gfx950 issues v_pk_add_f32 / v_pk_mul_f32 / v_pk_fma_f32 (two fp32 operations
+// per lane, one issue slot), and a complex value is such a pair.  For kernels bound by vector issue rather than by memory
+// (kh_chan2: ~70 % of its SIMD time is instruction issue, profiles/r03 counters): a 32-point transform is 259 vector
+// instructions instead of 420, a complex product 2-3 instead of 4.  Same operations per component, so the same roundings
+// up to how products and sums are fused.
+typedef float v2f __attribute__((ext_vector_type(2)));
+namespace pk {
+__device__ __forceinline__ v2f load(float2 t) { return (v2f){t.x, t.y}; }
+__device__ __forceinline__ float2 store(v2f t) { return make_float2(t.x, t.y); }
+// a * b
+__device__ __forceinline__ v2f cmul(v2f a, v2f b) {
+  v2f const asw = __builtin_shufflevector(a, a, 1, 0);
+  return __builtin_elementwise_fma(asw, (v2f){-b.y, b.y}, a * (v2f){b.x, b.x});
+}
+template <int SIGN>
+__device__ __forceinline__ v2f mul_w32(v2f x, int k) {
+  k &= 31;
+  if (k == 0) return x;
+  if (k == 16) return -x;
+  v2f const sw = __builtin_shufflevector(x, x, 1, 0);
+  if (k == 8) return SIGN > 0 ? (v2f){-sw.x, sw.y} : (v2f){sw.x, -sw.y};  // * (+-i)
+  if (k == 24) return SIGN > 0 ? (v2f){sw.x, -sw.y} : (v2f){-sw.x, sw.y}; // * (-+i)
+  float const c = (float)cos32(k), s = (float)(SIGN * sin32(k));
+  return __builtin_elementwise_fma(sw, (v2f){-s, s}, x * (v2f){c, c}); // (x.x c - x.y s, x.y c + x.x s)
+}
+template <int N, int SIGN, int LEN, int S>
+__device__ __forceinline__ void reg_pass(const v2f (&x)[N], v2f (&y)[N]) {
+  constexpr int RADIX = (LEN % 4 == 0) ? 4 : 2;
+  constexpr int NB = N / RADIX;
+  constexpr int TSTEP = 32 / LEN;
+#pragma unroll
+  for (int rest = 0; rest < NB; rest++) {
+    int const p = rest / S, q = rest % S;
+    int const o = q + S * RADIX * p;
+    if constexpr (RADIX == 4) {
+      v2f const a = x[rest], b = x[rest + NB], c = x[rest + 2 * NB], d = x[rest + 3 * NB];
+      v2f const apc = a + c, amc = a - c, bpd = b + d, bmd = b - d;
+      v2f const sw = __builtin_shufflevector(bmd, bmd, 1, 0);
+      v2f const jb = SIGN < 0 ? (v2f){sw.x, -sw.y} : (v2f){-sw.x, sw.y};
+      y[o] = apc + bpd;
+      y[o + S] = mul_w32<SIGN>(amc + jb, p * TSTEP);
+      y[o + 2 * S] = mul_w32<SIGN>(apc - bpd, 2 * p * TSTEP);
+      y[o + 3 * S] = mul_w32<SIGN>(amc - jb, 3 * p * TSTEP);
+    } else {
+      v2f const a = x[rest], b = x[rest + NB];
+      y[o] = a + b;
+      y[o + S] = mul_w32<SIGN>(a - b, p * TSTEP);
+    }
+  }
+}
+template <int N, int SIGN>
+__device__ __forceinline__ void reg_fft(v2f (&v)[N]) {
+  static_assert(N == 16 || N == 32, "packed register FFT sizes");
+  v2f t[N];
+  if constexpr (N == 16) {
+    reg_pass<N, SIGN, 16, 1>(v, t);
+    reg_pass<N, SIGN, 4, 4>(t, v);
+  } else {
+    reg_pass<N, SIGN, 32, 1>(v, t);
+    reg_pass<N, SIGN, 8, 4>(t, v);
+    reg_pass<N, SIGN, 2, 16>(v, t);
+#pragma unroll
+    for (int k = 0; k < N; k++) v[k] = t[k];
+  }
+}
+} // namespace pk
+
 } // namespace kh
