@@ -577,7 +577,7 @@ int launch_fm2(hipStream_t st, const float2 *baseband, size_t bb_stride, int ole
   int const G = olen / 8, ppw = 64 / G;
   // Channels per workgroup: one, or in a large bank (>= 1024 FM channels) as many as fill a wavefront's lanes with items.
   // Wavefronts: no more than give every item a group, and about as many as keep every workgroup resident at once (110
-  // VGPRs: 4 wavefronts per SIMD, 4096 on the chip).  Measured over the bench shapes (tools/micro/g8.sh): a quarter more
+  // VGPRs: 4 wavefronts per SIMD, 4096 on the chip).  Measured over the bench shapes (tools/micro/fm2_waves_sweep.sh): a quarter more
   // than fit is still better -- idle channels' workgroups are gone after 6 us, and a busy channel with 32 open blocks
   // needs groups more than it needs an early start (640 channels x 32 blocks: 4 wavefronts 45 us, 8: 31, 16: 42).
   // (KA9Q_HIP_FM2_WAVES, KA9Q_HIP_FM2_CPW: read at every launch -- the tests run one bank under several arrangements)
