@@ -144,15 +144,17 @@ def test_config4_64MSps_2pow20(hip):
     bank.close()
 
 
-def test_config4_full_size_properties(hip):
+@pytest.mark.parametrize("C", [512, 1536])
+def test_config4_full_size_properties(hip, C):
     """512 channels at N = 2^20 (one GPU's share of config 4), 4 blocks: (i) channel results do not depend on the
     other channels: a spot-checked channel equals the same channel computed alone; (ii) duplicate channels are
-    bit-identical; (iii) three spot-checked channels match the oracle."""
+    bit-identical; (iii) three spot-checked channels match the oracle.  1536 channels: the same with the FM demodulator's
+    arrangement for large banks (eight channels per workgroup from 1024 FM channels on)."""
     fs, L, M, D = 64_000_000, 524288, 524289, 2048
     N = L + M - 1
     olen = L // D
-    T, C = 4, 512
-    ks = list(range(-256, 256))
+    T = 4
+    ks = list(range(-C // 2, C // 2))
     ks[500] = ks[10]  # a duplicate
     strong = {ks[10]: 0.05, ks[100]: 0.03, ks[333]: 0.04}
     sigs = [(k, a, 400.0 + (k % 7) * 50, 2500.0) for k, a in strong.items()]
@@ -162,7 +164,7 @@ def test_config4_full_size_properties(hip):
         bank.set_channel(c, demod=hip.KH_DEMOD_FM, rotate=synth.rotate_for(k, 12500.0, N, fs), low=-5500.0, high=5500.0)
     bank.write_input(0, x)
     bank.execute(T)
-    full = {c: (bank.baseband(c, T), bank.pcm(c, T)) for c in (10, 100, 333, 500, 0, 511)}
+    full = {c: (bank.baseband(c, T), bank.pcm(c, T)) for c in (10, 100, 333, 500, 0, C - 1)}
     bank.close()
     assert np.array_equal(full[10][0], full[500][0]) and np.array_equal(full[10][1], full[500][1])
     assert np.abs(full[10][1]).max() > 500 and np.abs(full[0][1]).max() == 0  # open / squelched
