@@ -293,10 +293,8 @@ static void launch_chan2_rb(hipStream_t st, Chan2Args const &A, const N0Pass1Arg
   int const nchan_wg = (((nwaves + C2_WAVES - 1) / C2_WAVES) + 7) & ~7;
   N0Pass1Args const Z = n0 ? *n0 : N0Pass1Args{};
   int const extra = n0 ? n0->gx * n0->nblocks * n0->ninputs : 0;
-  static int const occ = getenv("KA9Q_HIP_C2_OCC") ? atoi(getenv("KA9Q_HIP_C2_OCC")) : 1; // experiment: forced waves per SIMD
-  if (occ == 4)
-    hipLaunchKernelGGL((kh_chan2<RB, 4>), dim3(nchan_wg + extra), dim3(64 * C2_WAVES), 0, st, A, Z, nchan_wg, nwaves);
-  else if (occ == 3)
+  static int const occ = getenv("KA9Q_HIP_C2_OCC") ? atoi(getenv("KA9Q_HIP_C2_OCC")) : 1; // experiment: 3 forces three wavefronts per SIMD (4 spilled and was slower: removed)
+  if (occ == 3)
     hipLaunchKernelGGL((kh_chan2<RB, 3>), dim3(nchan_wg + extra), dim3(64 * C2_WAVES), 0, st, A, Z, nchan_wg, nwaves);
   else
     hipLaunchKernelGGL((kh_chan2<RB, 1>), dim3(nchan_wg + extra), dim3(64 * C2_WAVES), 0, st, A, Z, nchan_wg, nwaves);

@@ -152,7 +152,7 @@ __device__ __forceinline__ void fm2_store_status(kh_status *p, kh_status const &
 // A workgroup of one wavefront does the work first and iterates after it.
 template <int G>
 __global__ __launch_bounds__(1024) void kh_fm_demod2(Fm2Args F, int nfm_wg, N0FinalArgs Z, int n_fm, int cpw, float r_lo, float r_hi) {
-  constexpr int K = 8, OLEN = K * G, PPW = 64 / G;
+  constexpr int K = 8, OLEN = K * G;
   static_assert(G == 32 || G == 64, "olen = 256 or 512");
   __shared__ double shB[FM2_MAXT]; // a block's integrator carry-out for a zero carry-in (0: closed)
   __shared__ __attribute__((aligned(16))) double sh_coef[KH_XI_SEGS * (KH_XI_DEG + 1)];
@@ -285,7 +285,7 @@ __global__ __launch_bounds__(1024) void kh_fm_demod2(Fm2Args F, int nfm_wg, N0Fi
     __builtin_amdgcn_s_sleep(1);
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
   KH_T(2)
-  int const n_open = sh_count[0], n_gen = sh_count[1], n_all = sh_count[2];
+  int const n_gen = sh_count[1], n_all = sh_count[2]; // (sh_count[0]: the open items, the first of the n_gen)
   unsigned long long const g4 = (unsigned long long)sh_gt4[0] | ((unsigned long long)sh_gt4[1] << 32);
   // the open items, then the closed ones that carry a decaying lastaudio: a group takes the next one of the list (in list
   // order: what an item waits for was taken before it, by a group that publishes before it waits)
