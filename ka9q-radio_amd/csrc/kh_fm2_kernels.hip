@@ -472,7 +472,8 @@ __global__ __launch_bounds__(1024) void kh_fm_demod2(Fm2Args F, int nfm_wg, N0Fi
       float mlane = INFINITY;
 #pragma unroll
       for (int j = 0; j < K; j++) mlane = fminf(mlane, thr[j]);
-      float cin = c_first, last_val = c_first;
+      float cin = c_first;
+      int has_end = 0, val_end = 0;
       for (int it = 0; it < G; it++) {
         float c = cin;
 #pragma unroll
@@ -500,12 +501,12 @@ __global__ __launch_bounds__(1024) void kh_fm_demod2(Fm2Args F, int nfm_wg, N0Fi
         int const hp = __builtin_amdgcn_update_dpp(0, has, 0x138, 0xf, 0xf, false); // wave_shr:1
         int const np_ = __builtin_amdgcn_update_dpp(0, val, 0x138, 0xf, 0xf, false);
         float const ncin = (hp && l != 0) ? __int_as_float(np_) : c_first;
-        last_val = __shfl(has, G - 1, G) ? __int_as_float(__shfl(val, G - 1, G)) : c_first;
+        has_end = has, val_end = val; // (of the last round run: read once, after the loop)
         bool const changed = __float_as_int(ncin) != __float_as_int(cin);
         cin = ncin;
         if (!__builtin_amdgcn_ballot_w64(changed)) break;
       }
-      pdev_neg = last_val;
+      pdev_neg = __shfl(has_end, G - 1, G) ? __int_as_float(__shfl(val_end, G - 1, G)) : c_first;
     }
     if (l == 0) {
       kh_status r{};
