@@ -607,7 +607,7 @@ def main():
 
     if rank == 0:
         bincount = N - (int((N * 5500.0) / FS) - int((N * -5500.0) / FS))
-        # compute_n0's second iteration: in the row pass itself (the default for four-step transforms: rendezvous at this size); with
+        # compute_n0's second iteration: prepared in the row pass (bracket mode, the default for four-step transforms); with
         # KA9Q_HIP_N0_DIRECT=0 it re-reads the spectrum inside the channel kernel's launch (kh_bank.cpp enqueue_back)
         n0_rides = (ND == 1024 and 2 * OLEN == ND and os.environ.get("KA9Q_HIP_RIDE_N0", "1") != "0"
                     and os.environ.get("KA9Q_HIP_CHAN_WAVE", "1") != "0" and os.environ.get("KA9Q_HIP_N0_DIRECT", "-1") == "0")
@@ -620,7 +620,7 @@ def main():
             empty["n0"] = "iteration 1 in chan (kh_chan2's launch), final sums in demod (kh_fm_demod2's launch)"
         elif ND == 1024 and 2 * OLEN == ND and os.environ.get("KA9Q_HIP_N0_DIRECT", "-1") != "0":
             empty["n0"] = ("first iteration and the bracket of the second in fft2 (kh_fft_rows), the exact threshold in chan (kh_chan2's "
-                           "launch), final sums in demod (kh_fm_demod2's launch)" if os.environ.get("KA9Q_HIP_N0_DIRECT", "-1") == "2" else
+                           "launch), final sums in demod (kh_fm_demod2's launch)" if os.environ.get("KA9Q_HIP_N0_DIRECT", "-1") != "1" else
                            "both iterations in fft2 (kh_fft_rows, rendezvous), final sums in demod (kh_fm_demod2's launch)")
         for name, (ms, n) in st.items():
             if n:

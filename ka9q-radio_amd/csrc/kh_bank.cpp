@@ -78,7 +78,7 @@ struct kh_bank {
   int nslots = 3; // ring depth of what the front half hands to the back half (KA9Q_HIP_SLOTS, 2..4)
   int fused_ingest = 1;   // policy (KA9Q_HIP_FUSED_INGEST)
   int ride_n0 = 1;        // policy (KA9Q_HIP_RIDE_N0)
-  int n0_direct_mode = -1; // policy (KA9Q_HIP_N0_DIRECT): 0 never, 1 rendezvous, 2 bracket, -1 (default) by transform size
+  int n0_direct_mode = -1; // policy (KA9Q_HIP_N0_DIRECT): 0 never, 1 rendezvous, 2 or -1 (default) bracket
   int n0_stagger = 0;      // KA9Q_HIP_N0_STAGGER (N0Fuse::stagger)
   int n0_spin = 1000;      // KA9Q_HIP_N0_SPIN: polls before a row-pass workgroup gives up (0: every block is re-read)
   bool fused_now = false; // this launch: large transform and no oscillator active
@@ -817,16 +817,17 @@ static bool n0_in_fft(const kh_bank *b) {
 // is most of the channel stage, 24.5 -> 13.8 us at configs[1], and the step 76-80 -> 63 us), so: every four-step size,
 // unless KA9Q_HIP_N0_DIRECT says 0 (never) or 1 (whenever possible).
 // Since then there is bracket mode as well (2, kh_n0.cuh), which needs no rendezvous: the row pass loses 3 us (N = 2^18) to
-// 9 us (N = 2^20) less than with the rendezvous, and the channel stage carries the second step, 2 to 6 us.  Measured per
-// step, rendezvous / bracket (several runs each): bench.py (N = 2^18) 62.1-62.9 / 62.6-63.2 us; N = 2^19, 256 NBFM channels
-// 124-129 / 126-139, config 3's mixed share 191.6 / 191.6; N = 2^20 135-138 / 130-133 (512 channels), 196-198 / 190-195
-// (4096).  So by default: the bracket from N = 2^20 on, the rendezvous below; KA9Q_HIP_N0_DIRECT = 1 / 2 selects one for
-// every size (2: no workgroup ever waits for another, and which path a block takes depends on its data alone), 0 neither.
+// 10 us (N = 2^20) less than with the rendezvous, the column pass adds the window's energy to its IF-power sum, and the
+// channel stage carries the second step, 1 to 4 us.  Measured per step, rendezvous / bracket (two runs each, the bracket
+// with its staging area private to a wavefront and the exclusion test only where it can bite): bench.py (N = 2^18)
+// 63.8-64.1 / 61.9-62.4 us; N = 2^19, 256 NBFM channels 128.8-128.9 / 129.3-130.1; config 3's mixed share 191.6 / 191.6;
+// N = 2^20 135-136 / 128.7-128.8 (512 channels), 196-198 / 190-195 (4096).  The bracket is the default at every four-step
+// size: no workgroup ever waits for another, and which path a block takes depends on its data alone (the rendezvous'
+// time-out does not).  KA9Q_HIP_N0_DIRECT = 1 selects the rendezvous, 0 neither.
 static int n0_direct(const kh_bank *b) {
   if (b->n0_direct_mode == 0 || !b->cfg.compute_n0 || b->N <= KH_MAX_SMALL_N) return 0;
   if (!n0_plan(b->N, b->cfg.samprate, b->cfg.n0_low, b->cfg.n0_high).valid) return 0;
-  if (b->n0_direct_mode == 1 || b->n0_direct_mode == 2) return b->n0_direct_mode;
-  return b->N >= (1 << 20) ? 2 : 1;
+  return b->n0_direct_mode == 1 ? 1 : 2;
 }
 // BACK: compute_n0 (radio.c:422-465), per channel filter output (filter.c:240-384), demodulators, scaleclip.
 static int enqueue_back(kh_bank *b, hipStream_t st, unsigned int nblocks, bool prof) {

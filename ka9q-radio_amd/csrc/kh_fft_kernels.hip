@@ -14,6 +14,7 @@
 #include "kh_fm.cuh"
 #include "../../include/ka9q_hip.h"
 #include <cstdlib>
+#include <type_traits>
 
 namespace kh {
 
@@ -291,7 +292,7 @@ __global__ __launch_bounds__(NT, 4) void kh_fft_cols(const float2 *__restrict__ 
   static_assert(I1 * NT == W * RB && I2 * NT == W * RA, "tile must divide evenly over the workgroup");
   constexpr int CS = RB * W + 16; // pitch of c: an odd multiple of 16 floats, so two c's in a 32-lane group differ in bank
   __shared__ float ex[RA * CS];
-  __shared__ float red[NT / 64];
+  __shared__ float red[2 * (NT / 64)];
   int const tid = threadIdx.x;
   // this launch handles blocks b0 .. b0 + gridDim.y - 1 of the nblocks of the call (kh_bank_execute); its scratch slot
   // in tmp is the block's index within the launch: the groups of a call reuse the same scratch
@@ -328,14 +329,18 @@ __global__ __launch_bounds__(NT, 4) void kh_fft_cols(const float2 *__restrict__ 
     }
     // IF power of the block's new samples (radio.c:188,197: n >= M-1) and the next launch's history (filter.c:230:
     // the last M-1 points of the launch = window elements n >= L of its last block)
-    float e = 0.f;
+    float e = 0.f, eh = 0.f; // new samples; the history part of the window (compute_n0's bracket wants both, kh_n0.cuh)
 #pragma unroll
     for (int u = 0; u < I1; u++)
 #pragma unroll
       for (int a = 0; a < RA; a++) {
         int const n = n_lane + (u * (NT / W) + RB * a) * N2;
         float2 const x = v[u][a];
-        if (n >= ing.M1) e += x.x * x.x + x.y * x.y;
+        float const p = x.x * x.x + x.y * x.y;
+        if (n >= ing.M1)
+          e += p;
+        else
+          eh += p;
       }
     if (b == nblocks - 1) { // uniform: window elements n >= L of the call's last block are the next history
       // element n - L of hist_out; n < L makes the offset negative, i.e. out of range: the buffer unit drops the store
@@ -350,10 +355,26 @@ __global__ __launch_bounds__(NT, 4) void kh_fft_cols(const float2 *__restrict__ 
         }
       }
     }
-    e = block_sum<NT>(e, red);
-    if (tid == 0) ing.energy_part[((size_t)i * nblocks + b) * gridDim.x + tile] = e;
+    { // both sums behind one pair of barriers
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) {
+        e += __shfl_xor(e, o, 64);
+        eh += __shfl_xor(eh, o, 64);
+      }
+      if ((tid & 63) == 0) red[tid >> 6] = e, red[NT / 64 + (tid >> 6)] = eh;
+      __syncthreads();
+      if (tid == 0) {
+        float te = 0.f, th = 0.f;
+#pragma unroll
+        for (int wv = 0; wv < NT / 64; wv++) te += red[wv], th += red[NT / 64 + wv];
+        ing.energy_part[((size_t)i * nblocks + b) * gridDim.x + tile] = te;
+        // compute_n0, bracket mode (kh_n0.cuh): the energy of the block's N window samples
+        if (ewin != nullptr) ewin[N0_SYNC_STRIDE * ((size_t)i * nblocks + b) + tile] = te + th;
+      }
+      __syncthreads();
+    }
   }
-  if (ewin != nullptr) { // uniform.  compute_n0, bracket mode (kh_n0.cuh): the energy of the block's N window samples
+  if (!INGEST && ewin != nullptr) { // uniform
     float e = 0.f;
 #pragma unroll
     for (int u = 0; u < I1; u++)
@@ -554,16 +575,23 @@ __global__ __launch_bounds__(NT, 4) void kh_fft_rows(const float2 *__restrict__ 
     int ncand = 0;
     unsigned inside = 0; // bit d: output d is a candidate
     static_assert(RB <= 32, "one bit per output");
+    auto classify = [&](auto narrow) {
 #pragma unroll
-    for (int d = 0; d < RB; d++) {
-      float const p = n0_power(z[d]);
-      bool const counts = n0_bin_counts(tile * W + w + N1 * (c + RA * d), (int)N, n0);
-      bool const below = counts && p < lo, cand = counts && !below && p < hi;
-      pw += counts ? p : 0.f;
-      slo += below ? p : 0.f;
-      clo += below ? 1.f : 0.f;
-      inside |= cand ? 1u << d : 0u;
-    }
+      for (int d = 0; d < RB; d++) {
+        float const p = n0_power(z[d]);
+        // (narrow: the excluded range around DC lies in the first and the last row of the N1 x N2 spectrum, k2 = 0 or N2 - 1)
+        bool const counts = (!decltype(narrow)::value || d == 0 || d == RB - 1) ? n0_bin_counts(tile * W + w + N1 * (c + RA * d), (int)N, n0) : true;
+        bool const below = counts && p < lo, cand = counts && !below && p < hi;
+        pw += counts ? p : 0.f;
+        slo += below ? p : 0.f;
+        clo += below ? 1.f : 0.f;
+        inside |= cand ? 1u << d : 0u;
+      }
+    };
+    if (n0.narrow) // uniform
+      classify(std::true_type{});
+    else
+      classify(std::false_type{});
     ncand = __popc(inside);
     // where this lane's candidates go: after those of the lanes before it
     int off = ncand;
@@ -575,25 +603,24 @@ __global__ __launch_bounds__(NT, 4) void kh_fft_rows(const float2 *__restrict__ 
     int const total = __shfl(off, 63, 64);
     off -= ncand;
     size_t const pt = (size_t)i * nblocks + b;
-    // candidates: staged in the wavefront's part of the exchange buffer (every wavefront has read its last value from it
-    // once the barrier below is passed), then written out 256 bytes at a time -- as 32 stores with two or three lanes
-    // each they cost more than the spectrum's own stores (N = 2^20: row pass 62 -> 79 us)
+    // candidates: staged in LDS, then written out 256 bytes at a time -- as 32 stores with two or three lanes each they cost
+    // more than the spectrum's own stores (N = 2^20: row pass 62 -> 79 us).  The staging area is the part of the exchange
+    // buffer that only this wavefront read in the last phase of the exchange (rows c = tid/16 = 4 wave .. 4 wave + 3): its
+    // own reads are behind it (a wavefront's LDS operations complete in order), nobody else touches it: no barrier.
     constexpr int NWV = NT / 64;
-    static_assert(RA * CS >= NWV * N0_CAPW, "the exchange buffer holds every wavefront's candidates");
+    static_assert(W == 16 && 4 * CS >= N0_CAPW, "a wavefront's four rows of the exchange buffer hold its candidates");
     int const K = gridDim.x * NWV, idx = tile * NWV + (tid >> 6);
     float *hdr = n0.cand + pt * ((size_t)K * (N0_CAPW + 3)); // [3][K]: candidates found, sum and count below the bracket
     float *region = hdr + 3 * (size_t)K + (size_t)idx * N0_CAPW;
-    float *stage = ex + (tid >> 6) * N0_CAPW;
+    float *stage = ex + (tid >> 6) * 4 * CS;
 #pragma unroll
     for (int d = 0; d < RB; d++) buf_store2<SPEC_AUX>(z[d], rout, (c * N1 + w) * 8, RA * d * N1 * 8); // X[k1 + N1*k2], k2 = c + RA*d
-    __syncthreads();
 #pragma unroll
     for (int d = 0; d < RB; d++)
       if (inside >> d & 1u) {
         if (off < N0_CAPW) stage[off] = n0_power(z[d]);
         off++;
       }
-    // (a wavefront's LDS operations complete in order: no barrier between its own writes and reads)
     int const nout = total < N0_CAPW ? total : N0_CAPW;
     for (int k = tid & 63; k < nout; k += 64) region[k] = stage[k];
 #pragma unroll
@@ -729,6 +756,13 @@ static int launch_rows(hipStream_t st, const float2 *tmp, float2 *spec, size_t s
   size_t const spec_bytes = (size_t)RA * RB * N1 * 8 * (size_t)nblocks * ninputs;            // of the whole call
   bool const nt = nt_env < 0 ? spec_bytes >= ((size_t)100 << 20) : nt_env != 0;
   dim3 const grid(N1 / TILE_W, gblocks, ninputs);
+  {
+    int const N = RA * RB * N1, E = N - n0.bincount; // excluded bins: E of them, cyclically before n0.start
+    int const first = ((n0.start - E) % N + N) % N, last = ((n0.start - 1) % N + N) % N;
+    auto edge = [&](int k) { return k < N1 ? -1 : k >= N - N1 ? 1 : 0; };
+    n0.narrow = E <= 2 * N1 && edge(first) != 0 && edge(last) != 0 &&
+                (edge(first) == edge(last) ? first <= last : edge(first) == 1);
+  }
   if constexpr (TILE_W * RA == NT) { // (one row of outputs per lane: the second iteration can stay in registers)
     if (n0.direct == 2 && nt)
       hipLaunchKernelGGL((kh_fft_rows<RA, RB, NT, 2, 2>), grid, dim3(NT), 0, st, tmp, spec, spec_in_stride, N1, tw, n0, b0, nblocks);

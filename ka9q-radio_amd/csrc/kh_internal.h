@@ -154,6 +154,7 @@ struct N0Fuse {
   // words), which bounds the threshold from above by Parseval; the row pass sums what lies below the bracket's lower
   // edge and stores the few bins inside the bracket (cand); the exact threshold is applied to those when it is known.
   float *ewin = nullptr, *cand = nullptr;
+  int narrow = 0; // (set by launch_rows) the excluded bins all lie in the spectrum's first or last row of N1 bins: only two of a lane's outputs can be excluded
 };
 constexpr int N0_SYNC_STRIDE = 64; // 32-bit words per (input, block) in N0Fuse::sync: lines of its own
 int n0_partials(int N);
