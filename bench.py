@@ -98,6 +98,7 @@ def build_bank(pyka9q, shape, plan, nblocks, payload=None, compute_n0=1):
     bank = pyka9q.Bank(shape.L, shape.M, shape.D, shape.P, len(plan), nblocks, shape.fs,
                        payload=pyka9q.KH_PT_CF32 if payload is None else payload, compute_n0=compute_n0, n0_low=-5500.0, n0_high=5500.0)
     bank.keep_audio(0)
+    bank.keep_spectrum(KEEP_SPECTRUM)  # 0: the row pass stores only the rows of the spectrum that the channels read
     if all(ch["demod"] == "fm" for ch in plan):
         bank.keep_baseband(0)  # FM: filter output -> discriminator inside one kernel; PCM + status are the outputs
     for c, ch in enumerate(plan):
@@ -105,7 +106,28 @@ def build_bank(pyka9q, shape, plan, nblocks, payload=None, compute_n0=1):
     return bank
 
 
-def stage_bytes(bincount, n0_rides):
+# PCM, channel status and input status are a bank's outputs; the N-bin spectrum of every block is an intermediate that only
+# kh_bank_read_spectrum hands out.  0 (--keep-spectrum 0, the default): four-step row passes store the rows of N1 bins that a
+# channel's filter output reads and nothing else (kh_bank_keep_spectrum; bit-identical PCM and status:
+# tests/test_gpu_keep_spectrum.py).  SURVEY.md 8(d)'s per-step bytes still count the whole spectrum's write.
+KEEP_SPECTRUM = 0
+
+
+def kept_spectrum_bins(n, nd, rotates):
+    """bins per block that the row pass stores with kh_bank_keep_spectrum(0): the rows (N1 bins) that hold the N_dec bins
+    around each channel's rotate, in groups of four rows (a row-pass wavefront's share: kh_fft_rows, SpecMask)"""
+    if n <= 8192:
+        return n
+    n1 = 1 << (int(np.log2(n)) // 2)
+    n2 = n // n1
+    groups = set()
+    for r in rotates:
+        for row in range((r - nd // 2) // n1, (r + nd // 2) // n1 + 1):
+            groups.add((row % n2) // 4)
+    return min(n, 4 * n1 * len(groups))
+
+
+def stage_bytes(bincount, n0_rides, kept_bins=None):
     """algorithmic bytes per launch of each stage of the headline shape (DESIGN.md 'Kernels'): what the kernel must read +
     write.  fft1 = kh_fft_cols reading the raw ring itself (8 B/sample cf32, N samples per block window) and writing the
     column-transformed block; chan = kh_back_a: per (channel, block) N_dec spectrum bins + N_dec response + the FM work
@@ -113,7 +135,7 @@ def stage_bytes(bincount, n0_rides):
     return {
         "ingest": T * L * (8 + 8),
         "fft1": T * 16 * N,
-        "fft2": T * 16 * N,
+        "fft2": T * (8 * N + 8 * (N if kept_bins is None else kept_bins)),
         "n0": T * 8 * bincount,
         "chan": C * T * (8 * ND + 8 * ND + 8 * OLEN) + (T * 8 * bincount if n0_rides else 0),
         "demod": C * T * (8 * OLEN + 2 * OLEN),
@@ -412,9 +434,12 @@ def main():
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--no-extra", action="store_true", help="skip the shapes and realtime legs")
     ap.add_argument("--blocks", type=int, default=T, help="blocks per step (per kh_bank_execute call)")
+    ap.add_argument("--keep-spectrum", type=int, default=0, choices=[0, 1],
+                    help="1: every launch stores the whole spectrum of every block (kh_bank_read_spectrum); 0: only the rows the channels read")
     ap.add_argument("--demod", default="fm", choices=["fm", "none"], help="diagnostic: 'none' runs the filter bank without demodulators")
     args = ap.parse_args()
     globals()["T"] = args.blocks
+    globals()["KEEP_SPECTRUM"] = args.keep_spectrum
 
     import torch
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -462,6 +487,7 @@ def main():
     bank = pyka9q.Bank(L, M, D, 1, C, T, FS, payload=pyka9q.KH_PT_CF32, compute_n0=1, n0_low=-5500.0, n0_high=5500.0)
     bank.keep_audio(0)
     bank.keep_baseband(0)  # FM: filter output -> discriminator inside one kernel; PCM + status are the outputs
+    bank.keep_spectrum(KEEP_SPECTRUM)
     for c, ch in enumerate(plan):
         bank.set_channel(c, demod=pyka9q.KH_DEMOD_FM if args.demod == "fm" else pyka9q.KH_DEMOD_NONE,
                          **workloads.channel_kwargs(ch))
@@ -611,7 +637,11 @@ def main():
         # KA9Q_HIP_N0_DIRECT=0 it re-reads the spectrum inside the channel kernel's launch (kh_bank.cpp enqueue_back)
         n0_rides = (ND == 1024 and 2 * OLEN == ND and os.environ.get("KA9Q_HIP_RIDE_N0", "1") != "0"
                     and os.environ.get("KA9Q_HIP_CHAN_WAVE", "1") != "0" and os.environ.get("KA9Q_HIP_N0_DIRECT", "-1") == "0")
-        sb = stage_bytes(bincount, n0_rides)
+        # (the library stores everything unless compute_n0 runs in bracket mode: kh_bank.cpp, masked_now)
+        sparse = (not KEEP_SPECTRUM and os.environ.get("KA9Q_HIP_KEEP_SPECTRUM", "0") == "0"
+                  and os.environ.get("KA9Q_HIP_N0_DIRECT", "-1") in ("-1", "2"))
+        kept = kept_spectrum_bins(N, ND, rots) if sparse else N
+        sb = stage_bytes(bincount, n0_rides, kept)
         stages = {}
         # stages whose work rides in another kernel still record an (empty) event pair of ~5 us: no rate for those
         fused_ingest = N > 8192 and os.environ.get("KA9Q_HIP_FUSED_INGEST", "1") != "0"
@@ -619,8 +649,9 @@ def main():
         if n0_rides:
             empty["n0"] = "iteration 1 in chan (kh_chan2's launch), final sums in demod (kh_fm_demod2's launch)"
         elif ND == 1024 and 2 * OLEN == ND and os.environ.get("KA9Q_HIP_N0_DIRECT", "-1") != "0":
-            empty["n0"] = ("first iteration and the bracket of the second in fft2 (kh_fft_rows), the exact threshold in chan (kh_chan2's "
-                           "launch), final sums in demod (kh_fm_demod2's launch)" if os.environ.get("KA9Q_HIP_N0_DIRECT", "-1") != "1" else
+            empty["n0"] = ("first iteration and the bracket of the second in fft2 (kh_fft_rows), the exact threshold " +
+                           ("behind it on the front stream (kh_n0_fix, inside fft2's event pair)" if sparse else "in chan (kh_chan2's launch)") +
+                           ", final sums in demod (kh_fm_demod2's launch)" if os.environ.get("KA9Q_HIP_N0_DIRECT", "-1") != "1" else
                            "both iterations in fft2 (kh_fft_rows, rendezvous), final sums in demod (kh_fm_demod2's launch)")
         for name, (ms, n) in st.items():
             if n:
@@ -681,6 +712,9 @@ def main():
             "config": {"workload": "configs[1]: 8 MS/s cf32 wideband, L=131072 M=131073 N=262144, D=256 -> 31.25 kS/s, "
                                    "64 NBFM 12.5 kHz channels per GPU, 32 blocks (4.19 MS, 0.524 s of signal) per step",
                        "blocks_per_step": T, "channels_per_gpu": C,
+                       "spectrum": (f"intermediate, not an output: the row pass stores the {kept} of {N} bins per block that lie in rows a channel's "
+                                    "filter output reads (kh_bank_keep_spectrum 0); PCM, status and n0 as with the whole spectrum kept "
+                                    "(tests/test_gpu_keep_spectrum.py)") if sparse else "all N bins of every block stored",
                        "sharding": "ka9q-radio_amd/shard.py: channels disjoint and contiguous in frequency per GPU, FFT recomputed per GPU",
                        "rank0_channels_k": [int(plan[0]["k"]), int(plan[-1]["k"])]},
             "channel_MS_per_s": round(world * C * args.steps * T * L / dt / 1e6, 1),

@@ -262,6 +262,12 @@ int kh_bank_keep_audio(kh_bank *, int enable);
  * output straight to the discriminator inside one kernel and only PCM + status leave it.  Channels with another
  * demodulator (or none) always store it. */
 int kh_bank_keep_baseband(kh_bank *, int enable);
+/* 1 (default): every launch leaves the whole N-bin spectrum of every block (kh_bank_read_spectrum; filter.c:217's fdomain).
+ * 0: four-step transforms (N > 8192) store only the rows of N1 bins that the channels' filter outputs read
+ * (filter.c:274-335) -- at BASELINE configs[1] a tenth of the spectrum -- and compute_n0 (radio.c:422-465) is finished from
+ * the transform's registers and scratch, so PCM, status and input status are what they are with 1; kh_bank_read_spectrum
+ * then fails.  No counterpart in the reference, whose single filter_out reads one master spectrum. */
+int kh_bank_keep_spectrum(kh_bank *, int enable);
 /* 1: the two halves of kh_bank_execute's kernel sequence are captured into hipGraphs the second time a launch shape
  * (nblocks, buffer parity) is seen and replayed from then on.  0 (default): plain launches -- with four to six
  * kernels per launch the replay costs the host more than the launches do (measured, tools/hostbound.py). */

@@ -126,6 +126,19 @@ struct kh_bank {
   bool chans_dirty = true;
   unsigned last_blocks = 0;
   int keep_audio = 1, keep_baseband = 1;
+  // kh_bank_keep_spectrum(bank, 0): a four-step row pass stores only the rows of the spectrum that the channels' filter
+  // outputs read (SpecMask, kh_internal.h); mask is rebuilt by upload_channels, masked_now is this launch's decision
+  int keep_spectrum = 1;
+  SpecMask mask{};
+  bool masked_now = false;
+  unsigned *d_arrive = nullptr;           // N0Fuse::arrive: N0_SYNC_STRIDE words per (input, block)
+  unsigned *h_fail = nullptr, *h_fail_dev = nullptr; // N0Fuse::host_fail: pinned, and its address as the device sees it
+  // A block whose bracket fails is finished by ONE row-pass workgroup (n0_repair_block): right, but slow.  When the count of
+  // such blocks has moved, the bank stores whole spectra for sparse_hold launches (the second step's ordinary re-read
+  // serves them), twice as long every time in a row, and tries again afterwards.
+  unsigned fail_seen = 0;
+  unsigned long long launch_no = 0, sparse_resume_at = 0, sparse_last_fail = 0;
+  unsigned sparse_hold = 0, sparse_hold_min = 64; // KA9Q_HIP_SPARSE_HOLD (0: never fall back to whole spectra)
   int rtp = 0;                       // PCM packetisation plan (audio.c:32-135) after every launch
   kh_rtp_chunk *d_rtp = nullptr;     // [C][rtp_stride]
   kh_rtp_state *d_rtpstate = nullptr;
@@ -135,7 +148,7 @@ struct kh_bank {
     unsigned nblocks;
     int cur, fmpar, sp;
     const void *raw;       // the raw ring the front half reads (kh_bank_stream_submit alternates between two)
-    bool pipelined, fused;
+    bool pipelined, fused, masked;
     int seen;              // launches seen with this key; -1: capture failed, stay eager
     hipGraphExec_t front, back;
   };
@@ -182,6 +195,7 @@ static void drop_graphs(kh_bank *b) { // anything a captured launch baked in has
 extern "C" {
 
 int kh_bank_stream_close(kh_bank *b);
+int kh_bank_keep_spectrum(kh_bank *b, int enable);
 int kh_bank_destroy(kh_bank *b) {
   if (!b) return 0;
   if (b->stream) hipStreamSynchronize(b->stream);
@@ -195,7 +209,7 @@ int kh_bank_destroy(kh_bank *b) {
   }
   void *ptrs[] = {b->d_raw,   b->d_time[0], b->d_time[1], b->d_tmp, b->d_chans, b->d_resp,
                   b->d_ddesc, b->d_dstate,  b->d_idesc,   b->d_bb,     b->d_audio,  b->d_pcm,    b->d_status,
-                  b->d_istatus, b->d_n0state, b->d_scalar,
+                  b->d_istatus, b->d_n0state, b->d_scalar, b->d_arrive,
                   b->d_lists,
                   b->d_fmstat, b->d_fmwork, b->d_fmcarry, b->d_decaypow, b->d_rtp, b->d_rtpstate};
   for (void *p : ptrs)
@@ -208,6 +222,7 @@ int kh_bank_destroy(kh_bank *b) {
   for (auto &e : b->idesc_ev)
     if (e) hipEventDestroy(e);
   if (b->h_idesc) hipHostFree(b->h_idesc);
+  if (b->h_fail) hipHostFree(b->h_fail);
   if (b->h_pcm) hipHostFree(b->h_pcm);
   for (auto &e : b->ev_front_done)
     if (e) hipEventDestroy(e);
@@ -326,6 +341,14 @@ kh_bank *kh_bank_create(const struct kh_bank_config *cfg) {
     A(&b->d_n0acc[k], (n0_part_floats() + (cfg->compute_n0 ? n0_cand_floats(N) : 0)) * P * T * sizeof(float), true);
   }
   A(&b->d_n0state, P * sizeof(float), false);
+  if (N > KH_MAX_SMALL_N && cfg->compute_n0) { // (kh_bank_keep_spectrum(bank, 0): arrival counters and the host's failure count)
+    A(&b->d_arrive, (size_t)P * T * N0_SYNC_STRIDE * sizeof(unsigned), true);
+    if (ok) ok = KH_HIP(hipHostMalloc((void **)&b->h_fail, 64, hipHostMallocMapped));
+    if (ok) {
+      *b->h_fail = 0;
+      ok = KH_HIP(hipHostGetDevicePointer((void **)&b->h_fail_dev, b->h_fail, 0));
+    }
+  }
   A(&b->d_scalar, sizeof(float), true);
   A(&b->d_lists, 3 * C * sizeof(int), true);
   A(&b->d_fmstat, C * T * sizeof(FmBlockStat), true);
@@ -359,6 +382,8 @@ kh_bank *kh_bank_create(const struct kh_bank_config *cfg) {
   if (const char *e = getenv("KA9Q_HIP_FUSED_INGEST")) b->fused_ingest = atoi(e);
   if (const char *e = getenv("KA9Q_HIP_RIDE_N0")) b->ride_n0 = atoi(e);
   if (const char *e = getenv("KA9Q_HIP_N0_DIRECT")) b->n0_direct_mode = atoi(e);
+  if (const char *e = getenv("KA9Q_HIP_KEEP_SPECTRUM")) kh_bank_keep_spectrum(b, atoi(e) != 0); // (A/B switch: the default)
+  if (const char *e = getenv("KA9Q_HIP_SPARSE_HOLD")) b->sparse_hold_min = (unsigned)atoi(e);
   if (const char *e = getenv("KA9Q_HIP_N0_SPIN")) b->n0_spin = std::min(std::max(atoi(e), 0), 100000);
   if (const char *e = getenv("KA9Q_HIP_N0_STAGGER")) b->n0_stagger = std::min(std::max(atoi(e), 0), 64);
   b->chans.assign(C, ChanDesc{0, 0, COMPLEX, 0});
@@ -751,6 +776,12 @@ static int upload_channels(kh_bank *b) {
   b->n_lin_nopll = b->n_lin;
   for (int ch = 0; ch < C; ch++)
     if (b->ddesc[ch].demod == KH_DEMOD_LINEAR && b->ddesc[ch].pll) b->lists[C + b->n_lin++] = ch;
+  // the bins a channel's filter output reads (filter.c:274-335: every in/out type combination stays within N_dec/2 of rotate)
+  spec_mask_clear(&b->mask);
+  // (a channel that was never set sits at rotate 0 and is computed like any other)
+  for (int ch = 0; ch < C; ch++)
+    spec_mask_add(&b->mask, b->N, (long long)b->chans[ch].rotate - b->ND / 2, (long long)b->chans[ch].rotate + b->ND / 2);
+  b->mask.on = 1;
   hipStream_t st = b->stream;
   bool ok = KH_HIP(hipMemcpyAsync(b->d_chans, b->chans.data(), C * sizeof(ChanDesc), hipMemcpyHostToDevice, st));
   ok = ok && KH_HIP(hipMemcpyAsync(b->d_ddesc, b->ddesc.data(), C * sizeof(DemodDesc), hipMemcpyHostToDevice, st));
@@ -796,8 +827,14 @@ static int enqueue_front(kh_bank *b, hipStream_t st, unsigned int nblocks, bool 
     nf.ewin = b->d_n0acc[sp] + PT * (N0_SLOTS + 2 * N0_GX); // (bracket mode: the same words, as floats)
     nf.cand = b->d_n0acc[sp] + (size_t)n0_part_floats() * P * b->T;
   }
+  // a bank that keeps only its channels' rows of the spectrum: the row pass finishes a block whose bracket fails itself
+  bool const masked = b->masked_now && n0_on;
+  if (masked) {
+    nf.arrive = b->d_arrive;
+    nf.host_fail = b->h_fail_dev;
+  }
   if (launch_forward_fft(st, time, b->time_stride, 0, b->d_spec[sp], b->d_tmp, b->spec_stride, N, L, nblocks, P,
-                         prof ? b->cur_ev[2] : nullptr, nf, fused ? &fi : nullptr))
+                         prof ? b->cur_ev[2] : nullptr, nf, fused ? &fi : nullptr, masked ? &b->mask : nullptr))
     return -1;
   // overlap-save history for the next call (filter.c:230), into the other buffer
   if (!fused && !fused_carry && launch_carry(st, time + need, b->d_time[b->cur ^ 1], b->time_stride * sizeof(float2),
@@ -847,8 +884,11 @@ static int enqueue_back(kh_bank *b, hipStream_t st, unsigned int nblocks, bool p
   const float *dcand = n0_direct(b) == 2 ? b->d_n0acc[sp] + (size_t)n0_part_floats() * P * b->T : nullptr;
   bool const ride = !in_fft && b->ride_n0 && chan_wave_supported(b->ND, b->olen) &&
                     n0_pass1_args(&z, n0spec, b->spec_stride, N, plan, b->d_n0acc[sp], nblocks, P, dsync, dcand);
+  // (a masked spectrum cannot be re-read: the row pass has finished the blocks whose bracket fails)
+  int const no_reread = b->masked_now && n0spec != nullptr && plan.valid;
+  if (ride) z.no_reread = no_reread;
   if (!ride && launch_n0(st, n0spec, b->spec_stride, N, b->cfg.samprate, plan, b->d_energy[sp], echunks, L, b->d_n0state,
-                         b->d_n0acc[sp], b->d_istatus, nblocks, P, in_fft ? 1 : 0, nullptr, dsync, dcand))
+                         b->d_n0acc[sp], b->d_istatus, nblocks, P, in_fft ? 1 : 0, nullptr, dsync, dcand, no_reread))
     return -1;
   if (prof) hipEventRecord(b->cur_ev[4], st);
   int taken = 0;
@@ -870,7 +910,7 @@ static int enqueue_back(kh_bank *b, hipStream_t st, unsigned int nblocks, bool p
   N0FinalArgs nf;
   bool const ride_final = ride && taken && b->n_fm > 0 && (back2 || fm_finish_wave_usable(b->olen, nblocks));
   if (ride && launch_n0(st, n0spec, b->spec_stride, N, b->cfg.samprate, plan, b->d_energy[sp], echunks, L, b->d_n0state,
-                        b->d_n0acc[sp], b->d_istatus, nblocks, P, taken, ride_final ? &nf : nullptr, dsync, dcand))
+                        b->d_n0acc[sp], b->d_istatus, nblocks, P, taken, ride_final ? &nf : nullptr, dsync, dcand, no_reread))
     return -1;
   if (prof) hipEventRecord(b->cur_ev[5], st);
   // A mixed bank's demodulators are independent kernels, each far from filling the chip (a workgroup per channel): the
@@ -993,6 +1033,23 @@ int kh_bank_execute(kh_bank *b, unsigned int nblocks) {
   b->fused_now = b->fused_ingest && b->N > KH_MAX_SMALL_N;
   for (int i = 0; i < P; i++)
     if (id[i].lo2.active || id[i].doppler.active) b->fused_now = false;
+  // rows of the spectrum no channel reads are not stored when nobody else wants them; built into the bracket form of the
+  // row pass only (its second iteration never re-reads the spectrum: kh_n0_fix), so a bank without compute_n0 keeps storing all
+  b->masked_now = !b->keep_spectrum && b->N > KH_MAX_SMALL_N && n0_direct(b) == 2 && b->d_arrive != nullptr;
+  if (b->masked_now) {
+    unsigned const f = __atomic_load_n(b->h_fail, __ATOMIC_RELAXED); // blocks the row pass had to finish alone, so far
+    if (f != b->fail_seen) {
+      b->fail_seen = f;
+      if (b->sparse_hold_min) {
+        bool const again = b->sparse_hold && b->launch_no - b->sparse_last_fail < 4ull * b->sparse_hold;
+        b->sparse_hold = again ? std::min(2 * b->sparse_hold, 4096u) : b->sparse_hold_min;
+        b->sparse_resume_at = b->launch_no + b->sparse_hold;
+      }
+      b->sparse_last_fail = b->launch_no;
+    }
+    if (b->launch_no < b->sparse_resume_at) b->masked_now = false;
+  }
+  b->launch_no++;
   if (sf != b->front && !KH_HIP(hipStreamSynchronize(b->front))) return -1; // an earlier pipelined front half
   // the back half that last read slot sp (nslots launches ago) must be done before the front half overwrites it.  With
   // two slots that back half ends about when this front half is dispatched, and a wait that really blocks across
@@ -1030,10 +1087,10 @@ int kh_bank_execute(kh_bank *b, unsigned int nblocks) {
     kh_bank::GraphEntry *g = nullptr;
     for (auto &x : b->graphs)
       if (x.nblocks == nblocks && x.cur == b->cur && x.fmpar == b->fm_parity && x.sp == sp && x.raw == b->d_raw &&
-          x.pipelined == (sf != sb) && x.fused == b->fused_now)
+          x.pipelined == (sf != sb) && x.fused == b->fused_now && x.masked == b->masked_now)
         g = &x;
     if (!g) { // first sight: run eagerly (this also warms the twiddle tables, which allocate)
-      b->graphs.push_back(kh_bank::GraphEntry{nblocks, b->cur, b->fm_parity, sp, b->d_raw, sf != sb, b->fused_now, 0, nullptr, nullptr});
+      b->graphs.push_back(kh_bank::GraphEntry{nblocks, b->cur, b->fm_parity, sp, b->d_raw, sf != sb, b->fused_now, b->masked_now, 0, nullptr, nullptr});
       g = &b->graphs.back();
     }
     rc = run_half(b, sf, nblocks, enqueue_front, &g->front, g->seen);
@@ -1121,6 +1178,10 @@ int kh_bank_read_input_status(kh_bank *b, unsigned int input, struct kh_input_st
 }
 int kh_bank_read_spectrum(kh_bank *b, unsigned int input, unsigned int block, kh_cf32 *out) {
   if (!b || input >= (unsigned)b->P || block >= (unsigned)b->T || !out) return -1;
+  if (b->masked_now) {
+    set_error("kh_bank_read_spectrum: the last launch kept only its channels' rows of the spectrum (kh_bank_keep_spectrum(bank, 0))");
+    return -1;
+  }
   return read_back(b, out, b->d_spec[b->last_sp] + input * b->spec_stride + (size_t)block * b->N, b->N * sizeof(float2));
 }
 int kh_bank_read_response(kh_bank *b, unsigned int ch, kh_cf32 *out, float *noise_gain_out) {
@@ -1174,6 +1235,12 @@ int kh_bank_read_rtp(kh_bank *b, unsigned int ch, struct kh_rtp_chunk *out, size
     if (n && read_back(b, out, b->d_rtp + (size_t)ch * b->rtp_stride, n * sizeof(kh_rtp_chunk))) return -1;
   }
   if (after && read_back(b, after, b->d_rtpstate + ch, sizeof(*after))) return -1;
+  return 0;
+}
+int kh_bank_keep_spectrum(kh_bank *b, int enable) {
+  if (!b) return -1;
+  b->keep_spectrum = enable != 0;
+  drop_graphs(b);
   return 0;
 }
 int kh_bank_keep_baseband(kh_bank *b, int enable) {

@@ -97,7 +97,7 @@ int launch_ingest(hipStream_t st, const void *raw, size_t raw_stride_bytes, int 
 // radio.c:197-202 block by block.
 // algorithmic bytes: 8*bincount
 __global__ __launch_bounds__(256) void kh_n0_pass1(N0Pass1Args Z) {
-  __shared__ float sh[16];
+  __shared__ float sh[N0_SH];
   n0_pass1_body(Z, blockIdx.x, sh);
 }
 
@@ -140,7 +140,7 @@ int n0_pass1_args(N0Pass1Args *z, const float2 *spec, size_t spec_in_stride, int
 }
 int launch_n0(hipStream_t st, const float2 *spec, size_t spec_in_stride, int N, int samprate, N0Plan plan,
               const float *energy_part, int echunks, int L, float *n0_state, float *part, void *input_status, int nblocks,
-              int ninputs, int pass1_done, N0FinalArgs *final_out, const unsigned *sync, const float *cand) {
+              int ninputs, int pass1_done, N0FinalArgs *final_out, const unsigned *sync, const float *cand, int no_reread) {
   if (nblocks <= 0 || ninputs <= 0) return 0;
   if (nblocks > N0_MAXB) {
     set_error("at most %d blocks per launch", N0_MAXB);
@@ -150,6 +150,7 @@ int launch_n0(hipStream_t st, const float2 *spec, size_t spec_in_stride, int N, 
   int const have_n0 = spec != nullptr;
   N0Pass1Args z;
   int const valid = n0_pass1_args(&z, spec, spec_in_stride, N, plan, part, nblocks, ninputs, sync, cand);
+  if (valid) z.no_reread = no_reread;
   if (valid && !pass1_done)
     hipLaunchKernelGGL(kh_n0_pass1, dim3(z.gx * nblocks * ninputs), dim3(256), 0, st, z);
   N0FinalArgs const F{part, energy_part, echunks, L, N, samprate, valid, have_n0, n0_state, status, nblocks, ninputs};

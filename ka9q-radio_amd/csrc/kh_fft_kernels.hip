@@ -464,25 +464,78 @@ __global__ __launch_bounds__(NT, 4) void kh_fft_cols(const float2 *__restrict__ 
   }
 }
 
+// ---- a bank that keeps only its channels' rows of the spectrum (SpecMask): compute_n0's second iteration must never need
+// the spectrum again.  Every row-pass workgroup counts itself in per block (n0.arrive) once its first-iteration sum is
+// visible; the one that arrives last -- nobody waits for anybody -- evaluates the bracket's condition exactly as the second
+// step will (kh_n0.cuh, n0_bracket_finish: same operands, same operations).  If it fails (more than a quarter of the power
+// inside the excluded range, or a wavefront's candidates beyond their slots) that workgroup takes the block's second
+// iteration itself: the row transforms once more from the scratch it has just read (the next column pass has not
+// started), the exact threshold applied as the outputs appear, the {sum, count} pairs where n0_pass1_reread would leave
+// them.  One workgroup for a whole block: right, slow and rare; the host sees the count of such blocks and keeps whole
+// spectra for a while instead (kh_bank.cpp).
+// Eight rows at a time through the LDS transform of kh_fft.cuh, 32 registers: the register transform of the pass itself,
+// inlined a second time, made the compiler spill 40-120 registers of the pass (as a called function: 900 bytes of stack per
+// lane); as a kernel of its own it cannot be launched on a condition only the device knows, and launched regardless it
+// waits for workgroup slots beside the next launch's column pass (measured: 5-10 us per step, on either stream).
+template <int R, int NT>
+__device__ __forceinline__ void n0_repair_block(const float2 *__restrict__ blk /*the block's N points of scratch*/, int N1, int ntiles,
+                                                const float2 *__restrict__ tw, float2 *buf /*8 R points of LDS*/, float *red,
+                                                N0Fuse const &n0, float th, float *p1) {
+  constexpr int W = TILE_W, G = 8; // rows per group
+  static_assert((G * R) % (2 * NT) == 0, "a group of rows divides evenly over the workgroup");
+  int const tid = threadIdx.x;
+  int const N = R * N1;
+  for (int tile = 0; tile < ntiles; tile++) {
+    float s = 0.f, cnt = 0.f;
+    for (int g = 0; g < W / G; g++) {
+      int const row0 = tile * W + g * G; // k1 of the group's first row
+      const float4 *src = reinterpret_cast<const float4 *>(blk + (size_t)row0 * R);
+      for (int k = tid; k < G * R / 2; k += NT) reinterpret_cast<float4 *>(buf)[k] = src[k];
+      __syncthreads();
+      lds_fft<R, G, NT, 1, R, false, -1>(buf, tw, tid); // row r of the group at buf + r*R, natural order on return
+      for (int k = tid; k < G * R; k += NT) {
+        float const p = n0_power(buf[k]);
+        int const bin = row0 + k / R + N1 * (k % R); // X[k1 + N1*k2]
+        if (n0_bin_counts(bin, N, n0) && p < th) { // radio.c:457-460
+          s += p;
+          cnt += 1.f;
+        }
+      }
+      __syncthreads();
+    }
+    s = block_sum<NT>(s, red);
+    cnt = block_sum<NT>(cnt, red);
+    if (tid == 0) p1[2 * tile] = s, p1[2 * tile + 1] = cnt;
+  }
+  if (tid >= ntiles && tid < N0_GX) reinterpret_cast<float2 *>(p1)[tid] = make_float2(0.f, 0.f); // kh_n0_final adds all N0_GX pairs
+}
+
 // SPEC_AUX: cache policy of the spectrum stores.  A launch whose spectrum alone is beyond ~100 MB (N >= 2^19 at the bench
 // shapes) stores it non-temporal (2): the spectrum is read once, much later, by the channel kernels, while the raw ring and
 // the intermediate of the transform are re-read at once and fit the 256 MiB Infinity Cache only if the spectrum does not
 // push them out.  Measured: config 3's share 176 -> 157 us/step, config 4's 164 -> 152; nothing at configs[1], where
 // everything fits (nt on the raw loads, or sc0 / sc1 on these stores, measured worse).
 // MODE: compute_n0's second iteration: 0 not here, 1 direct (rendezvous of the block's tiles), 2 bracket (kh_n0.cuh)
-template <int RA, int RB, int NT, int MODE, int SPEC_AUX>
+// MASKED: only the rows of X that SpecMask names are stored (kh_internal.h).  A wavefront's rows k2 = c + RA*d, c = tid/16,
+// are 4*wave .. 4*wave + 3 for every d, so whether store d goes out is a scalar bit: no register, no per-lane predicate.
+template <int RA, int RB, int NT, int MODE, int SPEC_AUX, bool MASKED = false>
 __global__ __launch_bounds__(NT, 4) void kh_fft_rows(const float2 *__restrict__ tmp, float2 *__restrict__ spec,
                                                   size_t spec_in_stride, int N1, const float2 *__restrict__ tw,
-                                                  N0Fuse n0, int b0, int nblocks) {
+                                                  N0Fuse n0, int b0, int nblocks, SpecMask sm) {
   constexpr int W = TILE_W, R = RA * RB;
   constexpr int I1 = W * RB / NT, I2 = W * RA / NT;
   static_assert(I1 * NT == W * RB && I2 * NT == W * RA, "tile must divide evenly over the workgroup");
+  // (bracket mode only: in the plain store loop of MODE 0 every form of the conditional store spilled 11-19 registers
+  // around the last transform, and a spill there waits for every store in flight)
+  static_assert(!MASKED || (I2 == 1 && MODE == 2 && RB <= 32 && NT / 64 <= 8), "the mask is one bit per store of a wavefront");
+  unsigned const need = MASKED ? sm.need[__builtin_amdgcn_readfirstlane(threadIdx.x >> 6)] : ~0u;
   constexpr int RP = RB + 1;  // pitch of a row: odd, so the 16 rows a 32-lane group reads differ in bank
   constexpr int CS = W * RP;  // pitch of c (an odd multiple of 16 floats)
-  __shared__ float ex[RA * CS];
+  __shared__ __attribute__((aligned(16))) float ex[RA * CS];
   __shared__ float red[NT / 64];
   __shared__ float th_sh;
   __shared__ int ok_sh, arrived_sh;
+  __shared__ int last_sh; // MASKED: this workgroup is the last of its block to arrive
   constexpr bool DIRECT = MODE == 1;
   if (DIRECT && threadIdx.x == 0) arrived_sh = 0; // (behind the exchange's barriers when it is used)
   int const tid = threadIdx.x;
@@ -613,8 +666,25 @@ __global__ __launch_bounds__(NT, 4) void kh_fft_rows(const float2 *__restrict__ 
     float *hdr = n0.cand + pt * ((size_t)K * (N0_CAPW + 3)); // [3][K]: candidates found, sum and count below the bracket
     float *region = hdr + 3 * (size_t)K + (size_t)idx * N0_CAPW;
     float *stage = ex + (tid >> 6) * 4 * CS;
+    if constexpr (MASKED) {
+      // arrival (see n0_repair_block), ahead of the stores so that lane 0's round trips overlap with the other wavefronts'
+      // stores: a wavefront whose candidates outgrow their slots says so first, then the tile's first-iteration sum goes
+      // out with agent scope and, once it has landed, the block's counter goes up
+      unsigned *arrive = n0.arrive + N0_SYNC_STRIDE * pt;
+      if ((tid & 63) == 0 && total > N0_CAPW) {
+        (void)__hip_atomic_fetch_add(arrive + 2, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
+      pw = block_sum<NT>(pw, red);
+      if (tid == 0) {
+        __hip_atomic_store(n0.part + pt * N0_SLOTS + tile, pw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        last_sh = __hip_atomic_fetch_add(arrive, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1;
+      }
+    }
 #pragma unroll
-    for (int d = 0; d < RB; d++) buf_store2<SPEC_AUX>(z[d], rout, (c * N1 + w) * 8, RA * d * N1 * 8); // X[k1 + N1*k2], k2 = c + RA*d
+    for (int d = 0; d < RB; d++)
+      if (!MASKED || (need >> d & 1u)) buf_store2<SPEC_AUX>(z[d], rout, (c * N1 + w) * 8, RA * d * N1 * 8); // X[k1 + N1*k2], k2 = c + RA*d
 #pragma unroll
     for (int d = 0; d < RB; d++)
       if (inside >> d & 1u) {
@@ -633,8 +703,32 @@ __global__ __launch_bounds__(NT, 4) void kh_fft_rows(const float2 *__restrict__ 
       hdr[K + idx] = slo;
       hdr[2 * K + idx] = clo;
     }
-    pw = block_sum<NT>(pw, red);
-    if (tid == 0) n0.part[pt * N0_SLOTS + tile] = pw;
+    if constexpr (!MASKED) {
+      pw = block_sum<NT>(pw, red);
+      if (tid == 0) n0.part[pt * N0_SLOTS + tile] = pw;
+    } else {
+      __syncthreads();
+      if (!last_sh) return; // uniform
+      // every tile of the block has arrived: the exact threshold and the bracket's condition, as n0_bracket_finish has them
+      int const ntiles = gridDim.x;
+      if (tid < 64) {
+        float t = tid < ntiles ? __hip_atomic_load(n0.part + pt * N0_SLOTS + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.f;
+        t = n0_wave_sum(t);
+        if (tid == 0) {
+          float const th = (t / n0.bincount) * 2; // radio.c:456,461
+          bool const bad = !(th >= thP * N0_BR_LO && th < thP * N0_BR_HI) ||
+                           __hip_atomic_load(n0.arrive + N0_SYNC_STRIDE * pt + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
+          th_sh = th;
+          ok_sh = !bad;
+          if (bad && n0.host_fail != nullptr) (void)__hip_atomic_fetch_add(n0.host_fail, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+      }
+      __syncthreads();
+      if (ok_sh) return; // uniform: the second step (next kernel on the other stream) finds the same and takes the candidates
+      static_assert(sizeof(ex) >= 8 * R * sizeof(float2), "eight rows fit the exchange buffer");
+      n0_repair_block<R, NT>(tmp + i * spec_in_stride + (size_t)bl * N, N1, ntiles, tw, reinterpret_cast<float2 *>(ex), red, n0, th_sh,
+                             n0.part1 + pt * (2 * N0_GX));
+    }
   } else {
   // ---- compute_n0, direct mode (N0Fuse)
   static_assert(I2 == 1, "direct mode keeps one row of outputs per lane");
@@ -749,7 +843,7 @@ static int launch_cols(hipStream_t st, const float2 *time, size_t in_stride, flo
 }
 template <int RA, int RB, int NT>
 static int launch_rows(hipStream_t st, const float2 *tmp, float2 *spec, size_t spec_in_stride, int N1, int nblocks,
-                       int ninputs, N0Fuse n0, int b0, int gblocks) {
+                       int ninputs, N0Fuse n0, int b0, int gblocks, const SpecMask *mask) {
   const float2 *tw = twiddle_table(RA * RB);
   if (!tw) return -1;
   static int const nt_env = getenv("KA9Q_HIP_SPEC_NT") ? atoi(getenv("KA9Q_HIP_SPEC_NT")) : -1; // -1: by size
@@ -763,21 +857,31 @@ static int launch_rows(hipStream_t st, const float2 *tmp, float2 *spec, size_t s
     n0.narrow = E <= 2 * N1 && edge(first) != 0 && edge(last) != 0 &&
                 (edge(first) == edge(last) ? first <= last : edge(first) == 1);
   }
+  SpecMask const all{{0, 0, 0, 0, 0, 0, 0, 0}, 0};
+  if constexpr (TILE_W * RA == NT) {
+    if (mask != nullptr && mask->on) { // (launch_forward_fft has checked: bracket mode, with the arrival counters)
+      if (nt)
+        hipLaunchKernelGGL((kh_fft_rows<RA, RB, NT, 2, 2, true>), grid, dim3(NT), 0, st, tmp, spec, spec_in_stride, N1, tw, n0, b0, nblocks, *mask);
+      else
+        hipLaunchKernelGGL((kh_fft_rows<RA, RB, NT, 2, 0, true>), grid, dim3(NT), 0, st, tmp, spec, spec_in_stride, N1, tw, n0, b0, nblocks, *mask);
+      return KH_HIP(hipGetLastError()) ? 0 : -1;
+    }
+  }
   if constexpr (TILE_W * RA == NT) { // (one row of outputs per lane: the second iteration can stay in registers)
     if (n0.direct == 2 && nt)
-      hipLaunchKernelGGL((kh_fft_rows<RA, RB, NT, 2, 2>), grid, dim3(NT), 0, st, tmp, spec, spec_in_stride, N1, tw, n0, b0, nblocks);
+      hipLaunchKernelGGL((kh_fft_rows<RA, RB, NT, 2, 2>), grid, dim3(NT), 0, st, tmp, spec, spec_in_stride, N1, tw, n0, b0, nblocks, all);
     else if (n0.direct == 2)
-      hipLaunchKernelGGL((kh_fft_rows<RA, RB, NT, 2, 0>), grid, dim3(NT), 0, st, tmp, spec, spec_in_stride, N1, tw, n0, b0, nblocks);
+      hipLaunchKernelGGL((kh_fft_rows<RA, RB, NT, 2, 0>), grid, dim3(NT), 0, st, tmp, spec, spec_in_stride, N1, tw, n0, b0, nblocks, all);
     else if (n0.direct && nt)
-      hipLaunchKernelGGL((kh_fft_rows<RA, RB, NT, 1, 2>), grid, dim3(NT), 0, st, tmp, spec, spec_in_stride, N1, tw, n0, b0, nblocks);
+      hipLaunchKernelGGL((kh_fft_rows<RA, RB, NT, 1, 2>), grid, dim3(NT), 0, st, tmp, spec, spec_in_stride, N1, tw, n0, b0, nblocks, all);
     else if (n0.direct)
-      hipLaunchKernelGGL((kh_fft_rows<RA, RB, NT, 1, 0>), grid, dim3(NT), 0, st, tmp, spec, spec_in_stride, N1, tw, n0, b0, nblocks);
+      hipLaunchKernelGGL((kh_fft_rows<RA, RB, NT, 1, 0>), grid, dim3(NT), 0, st, tmp, spec, spec_in_stride, N1, tw, n0, b0, nblocks, all);
     if (n0.direct) return KH_HIP(hipGetLastError()) ? 0 : -1;
   }
   if (nt)
-    hipLaunchKernelGGL((kh_fft_rows<RA, RB, NT, 0, 2>), grid, dim3(NT), 0, st, tmp, spec, spec_in_stride, N1, tw, n0, b0, nblocks);
+    hipLaunchKernelGGL((kh_fft_rows<RA, RB, NT, 0, 2>), grid, dim3(NT), 0, st, tmp, spec, spec_in_stride, N1, tw, n0, b0, nblocks, all);
   else
-    hipLaunchKernelGGL((kh_fft_rows<RA, RB, NT, 0, 0>), grid, dim3(NT), 0, st, tmp, spec, spec_in_stride, N1, tw, n0, b0, nblocks);
+    hipLaunchKernelGGL((kh_fft_rows<RA, RB, NT, 0, 0>), grid, dim3(NT), 0, st, tmp, spec, spec_in_stride, N1, tw, n0, b0, nblocks, all);
   return KH_HIP(hipGetLastError()) ? 0 : -1;
 }
 
@@ -826,9 +930,27 @@ int fft_group_blocks(int N, int nblocks, int ninputs) {
   return g < nblocks ? g : nblocks;
 }
 
+void spec_mask_clear(SpecMask *m) { *m = SpecMask{{0, 0, 0, 0, 0, 0, 0, 0}, 0}; }
+static int rows_ra(int N2) { return N2 >= 1024 ? 32 : N2 >= 256 ? 16 : 8; } // launch_rows' instances
+void spec_mask_add(SpecMask *m, int N, long long lo, long long hi) {
+  if (N <= KH_MAX_SMALL_N || hi < lo) return;
+  int const N1 = four_step_n1(N), N2 = N / N1, RA = rows_ra(N2);
+  if (hi - lo >= N) lo = 0, hi = N - 1;
+  long long const r0 = (lo >= 0 ? lo : lo - (N1 - 1)) / N1, r1 = (hi >= 0 ? hi : hi - (N1 - 1)) / N1; // floor
+  for (long long r = r0; r <= r1; r++) {
+    int const k2 = (int)(((r % N2) + N2) % N2);
+    m->need[(k2 % RA) / 4] |= 1u << (k2 / RA);
+  }
+}
+bool spec_mask_has_row(SpecMask const *m, int N, int row) {
+  if (!m->on || N <= KH_MAX_SMALL_N) return true;
+  int const N1 = four_step_n1(N), N2 = N / N1, RA = rows_ra(N2);
+  return row >= 0 && row < N2 && (m->need[(row % RA) / 4] >> (row / RA) & 1u);
+}
+
 int launch_forward_fft(hipStream_t st, const void *time, size_t in_stride, int real_input, float2 *spec, float2 *tmp,
                        size_t spec_in_stride, int N, int L, int nblocks, int ninputs, hipEvent_t mid_event, N0Fuse n0,
-                       const FftIngest *fi) {
+                       const FftIngest *fi, const SpecMask *mask) {
   bool const pow2 = N >= 256 && !(N & (N - 1)) && N <= (1 << 20);
   if (!pow2 && !make_any_plan(N).npass) {
     set_error("forward FFT size %d unsupported (a power of two in [256, 2^20], or factors 2, 3, 5, 7 and at most %d)", N,
@@ -876,7 +998,12 @@ int launch_forward_fft(hipStream_t st, const void *time, size_t in_stride, int r
   // back: a group's scratch is sized to stay in the 256 MiB Infinity Cache between the two, and every group of a call
   // reuses the same scratch, so most of that round trip never reaches HBM.
   int const group = fft_group_blocks(N, nblocks, ninputs);
-  unsigned *const n0sync = n0.direct == 1 ? n0.sync : nullptr;
+  if (mask != nullptr && mask->on && (n0.part == nullptr || n0.part1 == nullptr || n0.direct != 2 || n0.arrive == nullptr)) {
+    set_error("a masked spectrum needs compute_n0 in bracket mode");
+    return -1;
+  }
+  // (the column pass zeroes its blocks' words: the rendezvous' counter and flag, or a masked spectrum's arrival counters)
+  unsigned *const n0sync = n0.direct == 1 ? n0.sync : (mask != nullptr && mask->on) ? n0.arrive : nullptr;
   float *const ewin = n0.direct == 2 ? n0.ewin : nullptr;
   int rc = 0;
   for (int b0 = 0; b0 < nblocks && !rc; b0 += group) {
@@ -891,10 +1018,10 @@ int launch_forward_fft(hipStream_t st, const void *time, size_t in_stride, int r
     if (rc) return rc;
     if (mid_event && b0 == 0) hipEventRecord(mid_event, st);
     switch (N2) {
-    case 128: rc = launch_rows<8, 16, 128>(st, tmp, spec, spec_in_stride, N1, nblocks, ninputs, n0, b0, gb); break;
-    case 256: rc = launch_rows<16, 16, 256>(st, tmp, spec, spec_in_stride, N1, nblocks, ninputs, n0, b0, gb); break;
-    case 512: rc = launch_rows<16, 32, 256>(st, tmp, spec, spec_in_stride, N1, nblocks, ninputs, n0, b0, gb); break;
-    case 1024: rc = launch_rows<32, 32, 512>(st, tmp, spec, spec_in_stride, N1, nblocks, ninputs, n0, b0, gb); break;
+    case 128: rc = launch_rows<8, 16, 128>(st, tmp, spec, spec_in_stride, N1, nblocks, ninputs, n0, b0, gb, mask); break;
+    case 256: rc = launch_rows<16, 16, 256>(st, tmp, spec, spec_in_stride, N1, nblocks, ninputs, n0, b0, gb, mask); break;
+    case 512: rc = launch_rows<16, 32, 256>(st, tmp, spec, spec_in_stride, N1, nblocks, ninputs, n0, b0, gb, mask); break;
+    case 1024: rc = launch_rows<32, 32, 512>(st, tmp, spec, spec_in_stride, N1, nblocks, ninputs, n0, b0, gb, mask); break;
     default: rc = -1;
     }
   }

@@ -154,10 +154,27 @@ struct N0Fuse {
   // words), which bounds the threshold from above by Parseval; the row pass sums what lies below the bracket's lower
   // edge and stores the few bins inside the bracket (cand); the exact threshold is applied to those when it is known.
   float *ewin = nullptr, *cand = nullptr;
+  // a masked spectrum (SpecMask): per (input, block) N0_SYNC_STRIDE words -- [0] row tiles that have arrived, [1] spare,
+  // [2] wavefronts whose candidates outgrew their slots; zeroed by the column pass.  host_fail (may be null): a word in
+  // pinned host memory that counts the blocks whose bracket failed (kh_fft_rows, n0_repair_block)
+  unsigned *arrive = nullptr, *host_fail = nullptr;
   int narrow = 0; // (set by launch_rows) the excluded bins all lie in the spectrum's first or last row of N1 bins: only two of a lane's outputs can be excluded
 };
 constexpr int N0_SYNC_STRIDE = 64; // 32-bit words per (input, block) in N0Fuse::sync: lines of its own
 int n0_partials(int N);
+// Which rows of the four-step spectrum X[k1 + N1*k2] (row = k2, N1 bins) the row pass stores.  A bank whose spectrum
+// nobody else asks for (kh_bank_keep_spectrum(bank, 0)) needs only the rows its channels' filter outputs read
+// (filter.c:274-335: N_dec bins around `rotate`); compute_n0 (radio.c:422-465) then has to be finished from the row
+// pass's registers (bracket mode) and, for a block the bracket fails, by kh_n0_fix from the transform's scratch.
+// A row-pass wavefront holds rows 4*wave .. 4*wave + 3 (+ RA*d, d < RB): need[wave] bit d says whether it stores them.
+struct SpecMask {
+  unsigned need[8];
+  int on; // 0: every row is stored
+};
+void spec_mask_clear(SpecMask *m);
+// the rows that hold bins lo .. hi (inclusive; any integers, taken modulo N) of a four-step transform of N points
+void spec_mask_add(SpecMask *m, int N, long long lo, long long hi);
+bool spec_mask_has_row(SpecMask const *m, int N, int row);
 // fi != nullptr (N > KH_MAX_SMALL_N only): the first pass reads the raw ring itself instead of `time` -- wire format
 // -> float x gain_factor (radio.c:136-178; no oscillator: the caller uses launch_ingest when one is active), leaves
 // fused_ingest_tiles(N) IF-power partial sums per (input, block) and stores the last M-1 samples of the launch in
@@ -175,9 +192,12 @@ struct FftIngest {
   int M;
 };
 int fused_ingest_tiles(int N);
+// mask (may be null; four-step sizes only): only these rows of the spectrum are stored.  Needs compute_n0 in bracket mode
+// (n0.direct == 2) with n0.arrive and n0.part1: a block whose bracket fails is finished by the row pass itself
+// (n0_repair_block), and the second step must be told not to re-read the spectrum (N0Pass1Args::no_reread).
 int launch_forward_fft(hipStream_t st, const void *time, size_t in_stride, int real_input, float2 *spec, float2 *tmp,
                        size_t spec_in_stride, int N, int L, int nblocks, int ninputs, hipEvent_t mid_event, N0Fuse n0,
-                       const FftIngest *fi = nullptr);
+                       const FftIngest *fi = nullptr, const SpecMask *mask = nullptr);
 // bin-select x response x inverse transform.  out: cf32 (or f32 when out_type REAL) at
 // out + ch*out_stride + b*olen.
 // complex_out: 1 if no channel has out_type REAL (known on the host): shapes that have one then take the
@@ -221,7 +241,8 @@ int n0_pass1_args(N0Pass1Args *z, const float2 *spec, size_t spec_in_stride, int
 int launch_n0(hipStream_t st, const float2 *spec, size_t spec_in_stride, int N, int samprate, N0Plan plan,
               const float *energy_part, int echunks /*partial sums per (input, block)*/, int L, float *n0_state,
               float *part /*n0_part_floats() per (input,block)*/, void *input_status, int nblocks, int ninputs,
-              int pass1_done = 0, N0FinalArgs *final_out = nullptr, const unsigned *sync = nullptr, const float *cand = nullptr);
+              int pass1_done = 0, N0FinalArgs *final_out = nullptr, const unsigned *sync = nullptr, const float *cand = nullptr,
+              int no_reread = 0);
 int n0_cols_tiles(int N);     // column tiles (= window energy partials) per block of a four-step transform
 int n0_rows_waves(int N);     // wavefronts per row tile
 size_t n0_cand_floats(int N); // bracket mode: candidate floats per (input, block); 0 for single-workgroup transforms

@@ -20,6 +20,7 @@ struct N0Pass1Args {
   // bracket mode: cand != nullptr; sync then holds the column pass's window-energy partials (floats), ncols of them per block
   const float *cand;
   int ncols, nrows, rwaves; // column tiles, row tiles, wavefronts per row tile
+  int no_reread = 0;        // a masked spectrum (SpecMask): the row pass has finished every block whose bracket fails
 };
 
 // ---- bracket mode.  radio.c:451-462's second iteration keeps the bins below th = 2 x (mean of the counted bins), which
@@ -101,9 +102,10 @@ __device__ __forceinline__ void n0_bracket_issue(N0Pass1Args const &Z, int task,
   }
 }
 // true: done; false (uniform over the workgroup, and the same for every tile of the block): the block's second iteration
-// has to re-read the spectrum (n0_pass1_reread).  `sh` holds >= 16 floats.
+// has to re-read the spectrum (n0_pass1_reread).  `sh` holds >= N0_SH floats (workgroups of up to 8 wavefronts).
+constexpr int N0_SH = 24;
 __device__ __forceinline__ bool n0_bracket_finish(N0Pass1Args const &Z, int task, N0Early const &E, float *sh) {
-  float *ps = sh, *pc = sh + 4, *nsh = sh + 8;
+  float *ps = sh, *pc = sh + 8, *nsh = sh + 16;
   int const tid = threadIdx.x, nt = blockDim.x, nw = nt >> 6;
   int const slice = task % Z.gx, b = (task / Z.gx) % Z.nblocks, i = task / (Z.gx * Z.nblocks);
   size_t const pt = (size_t)i * Z.nblocks + b;
@@ -168,10 +170,10 @@ __device__ __forceinline__ bool n0_bracket_finish(N0Pass1Args const &Z, int task
 }
 
 // part layout: [0, PT*N0_SLOTS) first-pass sums (left by the forward transform); then PT*N0_GX pairs {sum1, count1}
-// (PT = ninputs*nblocks).  wg = slice + gx*(block + nblocks*input); 128 or 256 threads; `sh` holds >= 16 floats.
+// (PT = ninputs*nblocks).  wg = slice + gx*(block + nblocks*input); 128 or 256 threads; `sh` holds >= N0_SH floats.
 // algorithmic bytes: 8*bincount per (input, block)
 __device__ __forceinline__ void n0_pass1_reread(N0Pass1Args const &Z, int wg, float *sh) {
-  float *ps = sh, *pc = sh + 4;
+  float *ps = sh, *pc = sh + 8;
   int const tid = threadIdx.x, nt = blockDim.x, nw = nt >> 6;
   int const slice = wg % Z.gx, b = (wg / Z.gx) % Z.nblocks, i = wg / (Z.gx * Z.nblocks);
   const float2 *fd = Z.spec + (size_t)i * Z.spec_in_stride + (size_t)b * Z.N;
@@ -226,7 +228,7 @@ __device__ __forceinline__ void n0_pass1_body(N0Pass1Args const &Z, int wg, floa
   if (Z.cand != nullptr) { // bracket mode
     N0Early E;
     n0_bracket_issue(Z, wg, E);
-    if (n0_bracket_finish(Z, wg, E, sh)) return;
+    if (n0_bracket_finish(Z, wg, E, sh) || Z.no_reread) return; // (uniform)
   } else if (Z.sync != nullptr) {
     int const b = (wg / Z.gx) % Z.nblocks, i = wg / (Z.gx * Z.nblocks);
     if (Z.sync[N0_SYNC_STRIDE * ((size_t)i * Z.nblocks + b) + 1] == 0) return; // uniform: the row pass has taken this block's iteration

@@ -28,7 +28,7 @@ EXPORTS = [
     "kh_bank_debug_pending", "kh_bank_stream_open", "kh_bank_stream_slot", "kh_bank_stream_submit", "kh_bank_stream_close", "kh_bank_read_pcm_all",
     "kh_bank_execute", "kh_bank_sync", "kh_bank_read_baseband", "kh_bank_read_pcm", "kh_bank_read_audio",
     "kh_bank_read_status", "kh_bank_read_input_status", "kh_bank_read_spectrum", "kh_bank_read_response",
-    "kh_bank_pcm_device_ptr", "kh_bank_keep_audio", "kh_bank_keep_baseband", "kh_bank_channel_state_size", "kh_bank_get_channel_state", "kh_bank_set_channel_state", "kh_bank_use_graph", "kh_bank_stream", "kh_bank_profile", "kh_bank_stage_times",
+    "kh_bank_pcm_device_ptr", "kh_bank_keep_audio", "kh_bank_keep_baseband", "kh_bank_keep_spectrum", "kh_bank_channel_state_size", "kh_bank_get_channel_state", "kh_bank_set_channel_state", "kh_bank_use_graph", "kh_bank_stream", "kh_bank_profile", "kh_bank_stage_times",
     "kh_stage_kernel_name", "kh_bank_rtp_enable", "kh_bank_rtp_set_state", "kh_bank_read_rtp",
     "kh_afsk_create", "kh_afsk_destroy", "kh_afsk_write_pcm", "kh_afsk_pcm_device_ptr", "kh_afsk_commit_pcm",
     "kh_afsk_execute", "kh_afsk_sync", "kh_afsk_read_frames", "kh_afsk_read_bits", "kh_afsk_read_status",
@@ -182,6 +182,7 @@ def lib():
     L.kh_bank_rtp_set_state.argtypes = [C.c_void_p, C.c_uint, C.c_void_p]
     L.kh_bank_read_rtp.argtypes = [C.c_void_p, C.c_uint, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t), C.c_void_p]
     L.kh_bank_keep_baseband.argtypes = [C.c_void_p, C.c_int]
+    L.kh_bank_keep_spectrum.argtypes = [C.c_void_p, C.c_int]
     L.kh_bank_channel_state_size.argtypes = []
     L.kh_bank_channel_state_size.restype = C.c_size_t
     L.kh_bank_get_channel_state.argtypes = [C.c_void_p, C.c_uint, C.c_void_p, C.c_size_t]
@@ -482,6 +483,9 @@ class Bank:
 
     def keep_baseband(self, enable):
         _check(self.lib.kh_bank_keep_baseband(self.h, int(enable)), "kh_bank_keep_baseband")
+
+    def keep_spectrum(self, enable):
+        _check(self.lib.kh_bank_keep_spectrum(self.h, int(enable)), "kh_bank_keep_spectrum")
 
     def write_input_device(self, inp, dptr, count):
         _check(self.lib.kh_bank_write_input(self.h, inp, dptr, count), "kh_bank_write_input")

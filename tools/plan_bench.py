@@ -8,6 +8,7 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "ka9q-radio_amd"))
 import torch, pyka9q, workloads, bench
 key = sys.argv[1]
+bench.KEEP_SPECTRUM = int(os.environ.get("PLAN_KEEP_SPECTRUM", "0"))  # 1: the whole spectrum of every block is stored (A/B)
 steps = int(sys.argv[2]) if len(sys.argv) > 2 else 20
 jobs = {
     "c4share": (workloads.CONFIG4, lambda: workloads.shard_plan(workloads.config4_plan(), workloads.CONFIG4, 8, 3)[0], 16),
@@ -45,7 +46,7 @@ for _ in range(steps):
     step()
 bank.sync()
 dt = (time.perf_counter() - t0) / steps
-print(f"PLAN={key} channels={len(plan)} blocks={nb}: {dt*1e6:.1f} us/step")
+print(f"PLAN={key} channels={len(plan)} blocks={nb} keep_spectrum={bench.KEEP_SPECTRUM}: {dt*1e6:.1f} us/step")
 if os.environ.get("PLAN_STAGES"):  # per-stage HIP events, every kernel alone (one stream)
     bank.profile(1)
     for _ in range(5):
