@@ -650,7 +650,7 @@ def main():
             empty["n0"] = "iteration 1 in chan (kh_chan2's launch), final sums in demod (kh_fm_demod2's launch)"
         elif ND == 1024 and 2 * OLEN == ND and os.environ.get("KA9Q_HIP_N0_DIRECT", "-1") != "0":
             empty["n0"] = ("first iteration and the bracket of the second in fft2 (kh_fft_rows), the exact threshold " +
-                           ("behind it on the front stream (kh_n0_fix, inside fft2's event pair)" if sparse else "in chan (kh_chan2's launch)") +
+                           "in chan (kh_chan2's launch)" + (" after the block's last row tile has checked the bracket" if sparse else "") +
                            ", final sums in demod (kh_fm_demod2's launch)" if os.environ.get("KA9Q_HIP_N0_DIRECT", "-1") != "1" else
                            "both iterations in fft2 (kh_fft_rows, rendezvous), final sums in demod (kh_fm_demod2's launch)")
         for name, (ms, n) in st.items():

@@ -18,6 +18,7 @@ jobs = {
     "c2": (workloads.CONFIG2, lambda: workloads.config2_plan(64), 32),
 }
 shape, mkplan, nb = jobs[key]
+nb = int(os.environ.get("PLAN_BLOCKS", nb))  # blocks per step (A/B)
 plan = mkplan()
 torch.cuda.set_device(0)
 device = torch.device("cuda", 0)
