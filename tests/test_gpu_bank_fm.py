@@ -47,10 +47,13 @@ def _run_pair(hip, L, M, D, fs, chans, x, nblocks_per_call, calls, flat=0, n0=Fa
         g_aud = [bank.audio(c, T) for c in range(C)]
         g_st = [bank.status(c, T) for c in range(C)]
         g_ist = bank.input_status(0, T)
-        g_spec0 = bank.spectrum(0, 0)
+        try:
+            g_spec0 = bank.spectrum(0, 0)
+        except RuntimeError:  # a sweep under KA9Q_HIP_KEEP_SPECTRUM=0: the bank kept only its channels' rows (tools/soak_sparse.sh)
+            g_spec0 = None
         for b in range(T):
             outs, istat = pipe.run_block([seg[b * L:(b + 1) * L]])
-            if b == 0:
+            if b == 0 and g_spec0 is not None:
                 assert rel_rms(g_spec0, pipe.spectrum(0)) < 1e-5
             assert abs(g_ist[b]["if_power"] - istat[0][0]) <= 1e-4 * istat[0][0]
             if n0:
