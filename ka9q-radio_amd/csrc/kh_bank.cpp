@@ -14,8 +14,13 @@
 #include <cstdlib>
 #include <cstring>
 #include <algorithm>
+#include <atomic>
+#include <condition_variable>
+#include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
+#include <sched.h>
 
 #include "../../include/ka9q_hip.h"
 #include "kh_internal.h"
@@ -111,6 +116,8 @@ struct kh_bank {
   FmBlockStat *d_fmstat = nullptr; // FM path scratch (kh_internal.h)
   FmWork *d_fmwork = nullptr;
   double *d_fmcarry = nullptr, *d_decaypow = nullptr;
+  Fm2Carry *d_fm2x = nullptr; // kh_fm_demod2 with split channels (small banks): [C][T], marked with fm2_epoch
+  unsigned fm2_epoch = 0;
   int fm_parity = 0;
   // host
   std::vector<ChanDesc> chans;
@@ -143,6 +150,34 @@ struct kh_bank {
   kh_rtp_chunk *d_rtp = nullptr;     // [C][rtp_stride]
   kh_rtp_state *d_rtpstate = nullptr;
   int rtp_stride = 0;
+  // What a back half needs to know of the launch it belongs to (the caller moves on to the next launch's front half
+  // while the back half is being queued: BackEnq)
+  struct BackJob {
+    unsigned nblocks;
+    int sp, fm_parity;
+    bool fused_now, masked_now;
+  };
+  // KA9Q_HIP_ENQ_THREAD=1 (default 0): the back half's launches go through a thread of the bank's own.  The caller queues
+  // the front half (its kernels, the hand-over event), posts the job and returns; the thread queues the wait for that
+  // event, the back half and the slot's "done" event.  Measured at BASELINE configs[1] (tools/hostbound.py): kh_bank_execute
+  // takes the caller 18-22 us instead of 35-40 (bursts), 30 instead of 52 us per step in a long run -- and the step stays
+  // at 59 us, because the host was not what bound it: with no kernels at all the step's events and hand-overs take the
+  // queues 12.5 us, the front half's kernels alone make it 50.4, the back half's alone 34.3, both 59.2
+  // (KA9Q_HIP_DIAG_SKIP).  So it is off by default: it buys a caller that also moves packets 20 us per launch, not throughput.
+  // One job at a time: a job is posted only when the one before is queued, so everything the caller reads later
+  // (ev_back_done of a slot nslots launches ago, the streams it synchronises after quiet()) has been queued.
+  // Every other entry point that touches the back stream or the bank's channel state calls quiet() first.
+  struct BackEnq {
+    std::thread th;
+    std::mutex m;
+    std::condition_variable cv;
+    std::atomic<int> state{0}; // 0: idle; 1: a job is posted or being queued; 2: quit
+    BackJob job{};
+    int rc = 0;                // sticky until quiet() reports it
+    char err[512] = "";
+  };
+  BackEnq *enq = nullptr;
+  int enq_thread = 0;
   // hipGraph cache: the kernel sequence of one execute call, captured the second time a shape is seen
   struct GraphEntry {
     unsigned nblocks;
@@ -192,12 +227,90 @@ static void drop_graphs(kh_bank *b) { // anything a captured launch baked in has
   b->graphs.clear();
 }
 
+// ---- the thread that queues back halves (kh_bank::BackEnq)
+static int enqueue_back_job(kh_bank *b, hipStream_t st, kh_bank::BackJob const &j, bool prof);
+static void enq_main(kh_bank *b) {
+  kh_bank::BackEnq &w = *b->enq;
+  if (ensure_init()) { // (sets this thread's current device)
+    w.rc = -1;
+    snprintf(w.err, sizeof(w.err), "%s", ka9q_hip_last_error());
+  }
+  for (;;) {
+    int s = 0;
+    for (int i = 0; i < 40000 && (s = w.state.load(std::memory_order_acquire)) == 0; i++) __builtin_ia32_pause(); // ~0.2 ms
+    if (s == 0) {
+      std::unique_lock<std::mutex> lk(w.m);
+      w.cv.wait(lk, [&] { return w.state.load(std::memory_order_acquire) != 0; });
+      s = w.state.load(std::memory_order_acquire);
+    }
+    if (s == 2) return;
+    kh_bank::BackJob const j = w.job;
+    int rc = w.rc;
+    if (!rc) {
+      hipStream_t const sb = b->stream;
+      if (!KH_HIP(hipStreamWaitEvent(sb, b->ev_front_done[j.sp], 0))) rc = -1;
+      if (!rc) rc = enqueue_back_job(b, sb, j, false);
+      if (!rc && !KH_HIP(hipEventRecord(b->ev_back_done[j.sp], sb))) rc = -1;
+      if (rc) {
+        w.rc = rc;
+        snprintf(w.err, sizeof(w.err), "%s", ka9q_hip_last_error());
+      }
+    }
+    w.state.store(0, std::memory_order_release);
+  }
+}
+// waits until the thread has queued what it was given; -1 (once) if a back half failed there
+static int quiet(kh_bank *b) {
+  if (!b->enq) return 0;
+  kh_bank::BackEnq &w = *b->enq;
+  for (unsigned i = 0; w.state.load(std::memory_order_acquire) == 1; i++) {
+    if (i < 20000)
+      __builtin_ia32_pause();
+    else
+      sched_yield();
+  }
+  if (w.rc) {
+    set_error("%s", w.err);
+    w.rc = 0;
+    return -1;
+  }
+  return 0;
+}
+static int enq_post(kh_bank *b, kh_bank::BackJob const &j) {
+  if (!b->enq) {
+    b->enq = new kh_bank::BackEnq;
+    b->enq->th = std::thread(enq_main, b);
+  }
+  if (quiet(b)) return -1;
+  kh_bank::BackEnq &w = *b->enq;
+  {
+    std::lock_guard<std::mutex> lk(w.m);
+    w.job = j;
+    w.state.store(1, std::memory_order_release);
+  }
+  w.cv.notify_one();
+  return 0;
+}
+static void enq_stop(kh_bank *b) {
+  if (!b->enq) return;
+  (void)quiet(b);
+  {
+    std::lock_guard<std::mutex> lk(b->enq->m);
+    b->enq->state.store(2, std::memory_order_release);
+  }
+  b->enq->cv.notify_one();
+  b->enq->th.join();
+  delete b->enq;
+  b->enq = nullptr;
+}
+
 extern "C" {
 
 int kh_bank_stream_close(kh_bank *b);
 int kh_bank_keep_spectrum(kh_bank *b, int enable);
 int kh_bank_destroy(kh_bank *b) {
   if (!b) return 0;
+  enq_stop(b);
   if (b->stream) hipStreamSynchronize(b->stream);
   if (b->front) hipStreamSynchronize(b->front);
   kh_bank_stream_close(b);
@@ -211,7 +324,7 @@ int kh_bank_destroy(kh_bank *b) {
                   b->d_ddesc, b->d_dstate,  b->d_idesc,   b->d_bb,     b->d_audio,  b->d_pcm,    b->d_status,
                   b->d_istatus, b->d_n0state, b->d_scalar, b->d_arrive,
                   b->d_lists,
-                  b->d_fmstat, b->d_fmwork, b->d_fmcarry, b->d_decaypow, b->d_rtp, b->d_rtpstate};
+                  b->d_fmstat, b->d_fmwork, b->d_fmcarry, b->d_decaypow, b->d_rtp, b->d_rtpstate, b->d_fm2x};
   for (void *p : ptrs)
     if (p) hipFree(p);
   for (auto &e : b->ev)
@@ -354,6 +467,7 @@ kh_bank *kh_bank_create(const struct kh_bank_config *cfg) {
   A(&b->d_fmstat, C * T * sizeof(FmBlockStat), true);
   A(&b->d_fmwork, C * b->bb_stride * sizeof(FmWork), true);
   A(&b->d_fmcarry, C * T * sizeof(double), true);
+  A(&b->d_fm2x, C * T * sizeof(Fm2Carry), true);
   A(&b->d_decaypow, (b->olen + 1) * sizeof(double), false);
   b->rtp_stride = (int)(T * ((2 * b->olen + 479) / 480)); // stereo: 2 words per output sample
   A(&b->d_rtp, C * b->rtp_stride * sizeof(kh_rtp_chunk), true);
@@ -379,6 +493,7 @@ kh_bank *kh_bank_create(const struct kh_bank_config *cfg) {
   }
   if (const char *e = getenv("KA9Q_HIP_GRAPH")) b->use_graph = atoi(e);
   if (const char *e = getenv("KA9Q_HIP_PIPELINE")) b->pipeline = atoi(e);
+  if (const char *e = getenv("KA9Q_HIP_ENQ_THREAD")) b->enq_thread = atoi(e);
   if (const char *e = getenv("KA9Q_HIP_FUSED_INGEST")) b->fused_ingest = atoi(e);
   if (const char *e = getenv("KA9Q_HIP_RIDE_N0")) b->ride_n0 = atoi(e);
   if (const char *e = getenv("KA9Q_HIP_N0_DIRECT")) b->n0_direct_mode = atoi(e);
@@ -426,6 +541,7 @@ int kh_bank_set_channel(kh_bank *b, unsigned int ch, const struct kh_channel_con
     set_error("kh_bank_set_channel: filter edges outside +-0.5 of the output rate");
     return -1;
   }
+  if (quiet(b)) return -1; // (the thread that queues back halves reads the channel lists)
   hipStream_t st = b->stream;
   float gain = 1.f / (float)b->N;
   if (c->out_type == CROSS_CONJ) gain *= (float)M_SQRT1_2;
@@ -609,6 +725,7 @@ int kh_bank_stream_open(kh_bank *b, unsigned int depth) {
     set_error("kh_bank_stream_open: already open");
     return -1;
   }
+  if (quiet(b)) return -1;
   size_t const P = b->P;
   b->h_slot_bytes = b->raw_stride;
   bool ok = KH_HIP(hipHostMalloc((void **)&b->h_ring, (size_t)depth * P * b->h_slot_bytes, hipHostMallocMapped));
@@ -650,6 +767,7 @@ int kh_bank_stream_open(kh_bank *b, unsigned int depth) {
 }
 int kh_bank_stream_close(kh_bank *b) {
   if (!b) return 0;
+  (void)quiet(b);
   if (b->copy) hipStreamSynchronize(b->copy);
   if (b->front) hipStreamSynchronize(b->front);
   if (b->stream) hipStreamSynchronize(b->stream);
@@ -742,7 +860,7 @@ int kh_bank_debug_pending(kh_bank *b, char *buf, size_t n) {
 }
 // PCM of every channel of the last launch in one transfer: out[ch*nwords .. ] (host memory); synchronises
 int kh_bank_read_pcm_all(kh_bank *b, int16_t *out, size_t nwords) {
-  if (!b || !out || nwords > b->pcm_stride) return -1;
+  if (!b || !out || nwords > b->pcm_stride || quiet(b)) return -1;
   // through pinned memory: a strided copy into pageable memory goes row by row (measured: 4.4 ms for 640 rows of 1 KiB)
   if (!b->h_pcm) { // first use on a bank without a stream (kh_bank_stream_open allocates it): with the queues drained
     if (kh_bank_sync(b)) return -1;
@@ -796,8 +914,15 @@ static int upload_channels(kh_bank *b) {
 // FRONT: convert + mix (radio.c:136-191) and the forward transform (filter.c:212-238) into slot b->sp.
 static bool n0_in_fft(const kh_bank *b);
 static int n0_direct(const kh_bank *b);
+// KA9Q_HIP_DIAG_SKIP (measurement only, results are garbage): 1 queues no back-half kernels, 2 no front-half kernels --
+// what a step costs with one half's kernels alone, events and hand-overs as ever
+static int diag_skip() {
+  static int const v = getenv("KA9Q_HIP_DIAG_SKIP") ? atoi(getenv("KA9Q_HIP_DIAG_SKIP")) : 0;
+  return v;
+}
 static int enqueue_front(kh_bank *b, hipStream_t st, unsigned int nblocks, bool prof) {
   int const L = b->cfg.L, M = b->cfg.M, N = b->N, P = b->P, sp = b->sp;
+  if (diag_skip() & 2) return 0;
   size_t const need = (size_t)nblocks * L;
   float2 *time = b->d_time[b->cur];
   if (prof) hipEventRecord(b->cur_ev[0], st);
@@ -868,11 +993,16 @@ static int n0_direct(const kh_bank *b) {
 }
 // BACK: compute_n0 (radio.c:422-465), per channel filter output (filter.c:240-384), demodulators, scaleclip.
 static int enqueue_back(kh_bank *b, hipStream_t st, unsigned int nblocks, bool prof) {
-  int const L = b->cfg.L, N = b->N, P = b->P, C = b->C, sp = b->sp;
+  return enqueue_back_job(b, st, kh_bank::BackJob{nblocks, b->sp, b->fm_parity, b->fused_now, b->masked_now}, prof);
+}
+static int enqueue_back_job(kh_bank *b, hipStream_t st, kh_bank::BackJob const &job, bool prof) {
+  unsigned int const nblocks = job.nblocks;
+  int const L = b->cfg.L, N = b->N, P = b->P, C = b->C, sp = job.sp;
+  if (diag_skip() & 1) return 0;
   N0Plan const plan = n0_plan(N, b->cfg.samprate, b->cfg.n0_low, b->cfg.n0_high);
   // compute_n0's second iteration (radio.c:451-462) only reads the spectrum: it rides along in the channel kernel's
   // launch when that kernel is the wave-resident one; otherwise it is a kernel of its own, in front.
-  int const echunks = b->fused_now ? fused_ingest_tiles(N) : ingest_chunks(L);
+  int const echunks = job.fused_now ? fused_ingest_tiles(N) : ingest_chunks(L);
   const float2 *n0spec = b->cfg.compute_n0 ? b->d_spec[sp] : nullptr;
   N0Pass1Args z;
   // (transforms that fit one workgroup have taken the second iteration themselves, from LDS: enqueue_front)
@@ -885,7 +1015,7 @@ static int enqueue_back(kh_bank *b, hipStream_t st, unsigned int nblocks, bool p
   bool const ride = !in_fft && b->ride_n0 && chan_wave_supported(b->ND, b->olen) &&
                     n0_pass1_args(&z, n0spec, b->spec_stride, N, plan, b->d_n0acc[sp], nblocks, P, dsync, dcand);
   // (a masked spectrum cannot be re-read: the row pass has finished the blocks whose bracket fails)
-  int const no_reread = b->masked_now && n0spec != nullptr && plan.valid;
+  int const no_reread = job.masked_now && n0spec != nullptr && plan.valid;
   if (ride) z.no_reread = no_reread;
   if (!ride && launch_n0(st, n0spec, b->spec_stride, N, b->cfg.samprate, plan, b->d_energy[sp], echunks, L, b->d_n0state,
                          b->d_n0acc[sp], b->d_istatus, nblocks, P, in_fft ? 1 : 0, nullptr, dsync, dcand, no_reread))
@@ -935,12 +1065,14 @@ static int enqueue_back(kh_bank *b, hipStream_t st, unsigned int nblocks, bool p
   if (back2 && b->n_fm > 0 &&
       launch_fm2(st, b->d_bb, b->bb_stride, b->olen, nblocks, b->d_ddesc, b->d_dstate, b->keep_audio ? b->d_audio : nullptr, b->d_pcm,
                  b->pcm_stride, b->cfg.pcm_big_endian, b->d_status, b->T, b->d_lists, b->n_fm, b->d_fmstat, b->d_decaypow,
-                 b->fm_parity, ride_final ? &nf : nullptr))
+                 job.fm_parity, ride_final ? &nf : nullptr,
+                 b->use_graph ? nullptr : b->d_fm2x /* a captured launch would replay its epoch */,
+                 (++b->fm2_epoch ? b->fm2_epoch : ++b->fm2_epoch)))
     return -1;
   if (launch_demod(sl, b->d_bb, b->bb_stride, b->olen, nblocks, C, b->d_ddesc, b->d_dstate,
                    b->keep_audio ? b->d_audio : nullptr, b->d_pcm, b->pcm_stride, b->cfg.pcm_big_endian, b->d_status,
                    b->T, b->d_lists, back2 ? 0 : b->n_fm, b->d_lists + C, b->n_lin, b->d_lists + 2 * C, b->n_am,
-                   FmScratch{b->d_fmstat, b->d_fmwork, b->d_fmcarry, b->d_decaypow, b->fm_parity},
+                   FmScratch{b->d_fmstat, b->d_fmwork, b->d_fmcarry, b->d_decaypow, job.fm_parity},
                    (ride_final && !back2) ? &nf : nullptr, b->n_lin_nopll))
     return -1;
   if (fork) {
@@ -1010,7 +1142,7 @@ int kh_bank_execute(kh_bank *b, unsigned int nblocks) {
       set_error("kh_bank_execute: input %d holds %zu samples, %zu needed", i, b->fill[i], need);
       return -1;
     }
-  if (b->chans_dirty && upload_channels(b)) return -1;
+  if (b->chans_dirty && (quiet(b) || upload_channels(b))) return -1;
   bool const prof = b->profiling == 1;                  // every stage alone, one stream
   bool const prof2 = b->profiling == 2 && b->pipeline;  // the two-stream pipeline, with events
   hipStream_t const sb = b->stream;                                // back half
@@ -1070,6 +1202,8 @@ int kh_bank_execute(kh_bank *b, unsigned int nblocks) {
   }
 
   int rc = 0;
+  bool const threaded = !prof && !prof2 && sf != sb && !b->use_graph && b->enq_thread;
+  if (!threaded && quiet(b)) return -1; // (a launch after the mode has changed)
   if (prof) {
     b->cur_ev = b->ev;
     rc = enqueue_front(b, sf, nblocks, true);
@@ -1083,6 +1217,11 @@ int kh_bank_execute(kh_bank *b, unsigned int nblocks) {
       rc = -1;
     if (!rc) rc = enqueue_back(b, sb, nblocks, true);
     if (!rc) b->evp_pending[sp] = true;
+  } else if (threaded) {
+    rc = enqueue_front(b, sf, nblocks, false);
+    if (!rc && !KH_HIP(hipEventRecord(b->ev_front_done[sp], sf))) rc = -1;
+    // (the wait for that event, the back half and ev_back_done[sp]: enq_main)
+    if (!rc) rc = enq_post(b, kh_bank::BackJob{nblocks, sp, b->fm_parity, b->fused_now, b->masked_now});
   } else {
     kh_bank::GraphEntry *g = nullptr;
     for (auto &x : b->graphs)
@@ -1112,7 +1251,7 @@ int kh_bank_execute(kh_bank *b, unsigned int nblocks) {
   }
   if (rc) return rc;
   if (sf != sb) {
-    if (!KH_HIP(hipEventRecord(b->ev_back_done[sp], sb))) return -1;
+    if (!threaded && !KH_HIP(hipEventRecord(b->ev_back_done[sp], sb))) return -1;
     b->slot_used[sp] = true;
   }
   if (b->n_fm) b->fm_parity ^= 1;
@@ -1146,12 +1285,13 @@ int kh_bank_execute(kh_bank *b, unsigned int nblocks) {
 }
 
 int kh_bank_sync(kh_bank *b) {
-  if (!b) return -1;
+  if (!b || quiet(b)) return -1;
   if (!KH_HIP(hipStreamSynchronize(b->front))) return -1;
   return KH_HIP(hipStreamSynchronize(b->stream)) ? 0 : -1;
 }
 
 static int read_back(kh_bank *b, void *dst, const void *src, size_t bytes) {
+  if (quiet(b)) return -1;
   if (!KH_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, b->stream))) return -1;
   return KH_HIP(hipStreamSynchronize(b->stream)) ? 0 : -1;
 }
@@ -1199,19 +1339,19 @@ int kh_bank_pcm_device_ptr(kh_bank *b, void **dptr, size_t *words_per_channel) {
 void *kh_bank_stream(kh_bank *b) { return b ? (void *)b->stream : nullptr; }
 
 int kh_bank_keep_audio(kh_bank *b, int enable) {
-  if (!b) return -1;
+  if (!b || quiet(b)) return -1;
   b->keep_audio = enable != 0;
   drop_graphs(b);
   return 0;
 }
 int kh_bank_rtp_enable(kh_bank *b, int enable) {
-  if (!b) return -1;
+  if (!b || quiet(b)) return -1;
   b->rtp = enable != 0;
   drop_graphs(b);
   return 0;
 }
 int kh_bank_rtp_set_state(kh_bank *b, unsigned int ch, const struct kh_rtp_state *s) {
-  if (!b || !s || ch >= (unsigned)b->C) return -1;
+  if (!b || !s || ch >= (unsigned)b->C || quiet(b)) return -1;
   if (!KH_HIP(hipMemcpyAsync(b->d_rtpstate + ch, s, sizeof(*s), hipMemcpyHostToDevice, b->stream))) return -1;
   return KH_HIP(hipStreamSynchronize(b->stream)) ? 0 : -1;
 }
@@ -1238,19 +1378,19 @@ int kh_bank_read_rtp(kh_bank *b, unsigned int ch, struct kh_rtp_chunk *out, size
   return 0;
 }
 int kh_bank_keep_spectrum(kh_bank *b, int enable) {
-  if (!b) return -1;
+  if (!b || quiet(b)) return -1;
   b->keep_spectrum = enable != 0;
   drop_graphs(b);
   return 0;
 }
 int kh_bank_keep_baseband(kh_bank *b, int enable) {
-  if (!b) return -1;
+  if (!b || quiet(b)) return -1;
   b->keep_baseband = enable != 0;
   drop_graphs(b);
   return 0;
 }
 int kh_bank_use_graph(kh_bank *b, int enable) {
-  if (!b) return -1;
+  if (!b || quiet(b)) return -1;
   b->use_graph = enable != 0;
   if (!enable) drop_graphs(b);
   return 0;

@@ -23,6 +23,7 @@
 #include "kh_fm.cuh"
 #include "kh_n0.cuh"
 #include "../../include/ka9q_hip.h"
+#include <algorithm>
 #include <cstdlib>
 
 namespace kh {
@@ -99,6 +100,12 @@ struct Fm2Args {
   kh_status *status;
   int status_stride;
   const int *list;
+  // splits > 1 (one-channel workgroups only): a channel's blocks are dealt in contiguous runs over `splits` neighbouring
+  // workgroups; the carry-outs of the runs before a workgroup's own reach it through xch ([channel][stat_stride]),
+  // marked with this launch's epoch
+  int splits;
+  unsigned epoch;
+  Fm2Carry *xch;
 };
 
 template <int G>
@@ -150,6 +157,17 @@ __device__ __forceinline__ void fm2_store_status(kh_status *p, kh_status const &
 //      the wait ends; it is bounded all the same).  Then the closed items that carry a decaying lastaudio (fm.c:124-132),
 //      then 16-byte zero stores for the idle ones.  An SNR wavefront that is done takes items as well.
 // A workgroup of one wavefront does the work first and iterates after it.
+//
+// Small banks (F.splits > 1): a workgroup per channel keeps only as many CUs busy as the bank has FM channels, and a busy
+// channel's 32 blocks are ~1200 vector instructions each on ONE CU's four SIMDs (64 channels x 32 open blocks: 18 us of
+// issue time there while three quarters of the chip idle).  The channel's blocks then go to `splits` workgroups with
+// neighbouring numbers, a contiguous run of blocks each.  Everything that depends on the whole launch is cheap and every
+// workgroup of the channel repeats it (statistics, squelch, which items are idle); what a block needs of the blocks before
+// it is their carry-outs for a zero carry-in (fm.c:110-111 is linear in lastaudio), which do NOT depend on each other:
+// a group publishes its block's in global memory (value, then this launch's epoch as the flag: agent-scope atomics, no
+// cache line that anybody reads with plain loads) and fetches those of the runs before its own.  A workgroup only ever
+// waits for workgroups with LOWER numbers, which the dispatcher has started before it; the wait is bounded all the same.
+// Same arithmetic in the same order whatever the split: tests/test_gpu_bank_fm.py holds the arrangements to bit identity.
 template <int G>
 __global__ __launch_bounds__(1024) void kh_fm_demod2(Fm2Args F, int nfm_wg, N0FinalArgs Z, int n_fm, int cpw, float r_lo, float r_hi) {
   constexpr int K = 8, OLEN = K * G;
@@ -161,14 +179,19 @@ __global__ __launch_bounds__(1024) void kh_fm_demod2(Fm2Args F, int nfm_wg, N0Fi
   __shared__ int sh_count[3];
   __shared__ unsigned sh_gt4[2], sh_ready[2], sh_listed; // per item: SNR above 4; carry-out published; (flag) the list stands
   __shared__ int sh_next[2];                              // tickets: the next entry of the list (open + decaying; idle)
+  __shared__ unsigned sh_open[2];                         // per item: squelch open (every item of the channels, not only this workgroup's)
   __shared__ Fm2Chan sh_ch[FM2_MAXCPW];
-  if ((int)blockIdx.x >= nfm_wg) { // kh_n0_final's work (one workgroup per input) rides in this launch
-    n0_final_body(Z, blockIdx.x - nfm_wg, sh_r, sh_bbp);
+  int const S = F.splits; // (1 whenever cpw > 1)
+  if ((int)blockIdx.x >= nfm_wg * S) { // kh_n0_final's work (one workgroup per input) rides in this launch
+    n0_final_body(Z, blockIdx.x - nfm_wg * S, sh_r, sh_bbp);
     return;
   }
   KH_T(0)
   int const lane64 = threadIdx.x & 63, wave = threadIdx.x >> 6, nwv = blockDim.x >> 6;
   int const par = F.par, nblocks = F.nblocks, items = cpw * nblocks; // items <= 64
+  // this workgroup's place among the channels' workgroups, and its run of blocks [b_lo, b_hi)
+  int const wgc = S > 1 ? (int)blockIdx.x / S : (int)blockIdx.x, part = (int)blockIdx.x - wgc * S;
+  int const b_lo = S > 1 ? part * nblocks / S : 0, b_hi = S > 1 ? (part + 1) * nblocks / S : nblocks;
   double const Ablk = F.decay_pow[OLEN];
   // roles
   int const nws = (cpw > 1 || nwv < 4) ? 1 : (nwv < 8 ? 2 : 4); // wavefronts that iterate: no more than half, one per SIMD
@@ -184,7 +207,7 @@ __global__ __launch_bounds__(1024) void kh_fm_demod2(Fm2Args F, int nfm_wg, N0Fi
   bool it_valid = false;
   {
     if ((int)threadIdx.x < cpw) {
-      int const chi = threadIdx.x * nfm_wg + blockIdx.x; // neighbouring channels (busy together, if any are) go to different workgroups
+      int const chi = threadIdx.x * nfm_wg + wgc; // neighbouring channels (busy together, if any are) go to different workgroups
       Fm2Chan c{};
       c.ch = -1;
       if (chi < n_fm) {
@@ -199,13 +222,13 @@ __global__ __launch_bounds__(1024) void kh_fm_demod2(Fm2Args F, int nfm_wg, N0Fi
     for (int k = threadIdx.x; k < KH_XI_SEGS * (KH_XI_DEG + 1); k += blockDim.x) sh_coef[k] = (&kh_xi_coeffs[0][0])[k];
     if (threadIdx.x == 0) sh_listed = 0u, sh_next[0] = 0, sh_next[1] = 0;
     if (es < items) {
-      int const ce = es / nblocks, be = es - ce * nblocks, che = ce * nfm_wg + blockIdx.x;
+      int const ce = es / nblocks, be = es - ce * nblocks, che = ce * nfm_wg + wgc;
       if (che < n_fm) {
         const FmBlockStat *fs = F.stat + (size_t)F.list[che] * F.stat_stride + be;
-        float const bbp = fs->bb_power, var = fs->variance;
-        r_it = fs->snr;
-        it_valid = true;
-        sh_bbp[es] = bbp, sh_var[es] = var, sh_r[es] = r_it;
+        float const bbp = fs->bb_power, var = fs->variance, r = fs->snr;
+        sh_bbp[es] = bbp, sh_var[es] = var, sh_r[es] = r;
+        it_valid = be >= b_lo && be < b_hi; // (the iteration and its status word: this workgroup's blocks only)
+        r_it = it_valid ? r : 0.f;
       }
     }
     __syncthreads(); // the only barrier
@@ -235,7 +258,8 @@ __global__ __launch_bounds__(1024) void kh_fm_demod2(Fm2Args F, int nfm_wg, N0Fi
   };
   if (wave == 0) { // (a work wavefront in either arrangement)
     int const e = lane64, ce = e / nblocks, b = e - ce * nblocks;
-    bool const valid = e < items && ce * nfm_wg + (int)blockIdx.x < n_fm;
+    bool const valid = e < items && ce * nfm_wg + wgc < n_fm;
+    bool const mine = valid && b >= b_lo && b < b_hi;
     float const r = valid ? sh_r[e] : 0.f;
     bool gt = r > r_hi; // (also r > 100, where fm_snr returns r)
     if (valid && !gt && r >= r_lo) gt = fmaxf(0.0f, (float)fm_snr_lane((double)r, sh_coef)) > 4.f; // (~8 rounds there)
@@ -250,21 +274,26 @@ __global__ __launch_bounds__(1024) void kh_fm_demod2(Fm2Args F, int nfm_wg, N0Fi
     // olen zeros of PCM below; in a large bank that is nearly every item.
     bool const idle = valid && !open &&
                       (C.flat || (C.lastaudio_in == 0.f && !(mo & ((1ull << e) - (1ull << (e - b))))));
-    unsigned long long const mg = __builtin_amdgcn_ballot_w64(valid && !open && !idle), mi = __builtin_amdgcn_ballot_w64(idle);
+    // the lists hold this workgroup's items only (all of them unless the channel is split)
+    unsigned long long const mo_m = __builtin_amdgcn_ballot_w64(mine && open);
+    unsigned long long const mg = __builtin_amdgcn_ballot_w64(mine && !open && !idle), mi = __builtin_amdgcn_ballot_w64(mine && idle);
     unsigned long long const below = (1ull << e) - 1;
-    int const no = __popcll(mo), ng = __popcll(mg);
-    if (valid)
-      sh_list[open ? __popcll(mo & below) : !idle ? no + __popcll(mg & below) : no + ng + __popcll(mi & below)] = (unsigned char)e;
+    int const no = __popcll(mo_m), ng = __popcll(mg);
+    if (mine)
+      sh_list[open ? __popcll(mo_m & below) : !idle ? no + __popcll(mg & below) : no + ng + __popcll(mi & below)] = (unsigned char)e;
     shB[e] = 0.0;
     if (e == 0) {
       sh_count[0] = no, sh_count[1] = no + ng, sh_count[2] = no + ng + __popcll(mi);
       sh_gt4[0] = (unsigned)g4, sh_gt4[1] = (unsigned)(g4 >> 32);
-      sh_ready[0] = ~(unsigned)mo, sh_ready[1] = ~(unsigned)(mo >> 32); // a closed block's carry-out is 0: ready
+      sh_open[0] = (unsigned)mo, sh_open[1] = (unsigned)(mo >> 32);
+      // a closed block's carry-out is 0: ready; so is, as far as the wait inside the workgroup goes, a block of another
+      // run (its carry-out is fetched from global memory before that wait)
+      sh_ready[0] = ~(unsigned)mo_m, sh_ready[1] = ~(unsigned)(mo_m >> 32);
     }
     // (a wavefront's LDS operations complete in order: the flag follows everything above)
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     if (e == 0) __hip_atomic_store(&sh_listed, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-    if (idle) {
+    if (mine && idle) {
       kh_status st_{};
       st_.bb_power = sh_bbp[e];
       st_.foffset = NAN; // fm.c:116,121 leave both untouched while the squelch is closed
@@ -287,6 +316,7 @@ __global__ __launch_bounds__(1024) void kh_fm_demod2(Fm2Args F, int nfm_wg, N0Fi
   KH_T(2)
   int const n_gen = sh_count[1], n_all = sh_count[2]; // (sh_count[0]: the open items, the first of the n_gen)
   unsigned long long const g4 = (unsigned long long)sh_gt4[0] | ((unsigned long long)sh_gt4[1] << 32);
+  bool fetched = false; // (split channels) this group has the carry-outs of the runs before b_lo in shB
   // the open items, then the closed ones that carry a decaying lastaudio: a group takes the next one of the list (in list
   // order: what an item waits for was taken before it, by a group that publishes before it waits)
   for (;;) {
@@ -364,12 +394,37 @@ __global__ __launch_bounds__(1024) void kh_fm_demod2(Fm2Args F, int nfm_wg, N0Fi
     }
     if (open && !flat) { // publish the carry-out
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-      if (l == 0) __hip_atomic_fetch_or(&sh_ready[e >> 5], 1u << (e & 31), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      if (l == 0) {
+        __hip_atomic_fetch_or(&sh_ready[e >> 5], 1u << (e & 31), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (part < S - 1) { // the runs after this one need it: the value, and once it has landed the flag
+          Fm2Carry *xc = F.xch + (size_t)ch * F.stat_stride + b;
+          __hip_atomic_store(&xc->B, (unsigned long long)__double_as_longlong(Bsum), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          __hip_atomic_store(&xc->epoch, F.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+      }
     }
     // lastaudio on entry to this block: the channel's blocks before it, each c <- decay^olen c + B (fm.c:110-111,130);
     // the open ones among them stand earlier in the list
     double c_in = (double)C.lastaudio_in;
     if (!flat) {
+      if (b_lo > 0 && !fetched) { // (S > 1, hence one channel: item e is block e) the open blocks of the runs before
+        fetched = true;
+        unsigned long long const mo_all = (unsigned long long)sh_open[0] | ((unsigned long long)sh_open[1] << 32);
+        for (int j = l; j < b_lo; j += G)
+          if (mo_all >> j & 1) {
+            Fm2Carry *xc = F.xch + (size_t)ch * F.stat_stride + j;
+            for (int spin = 0; spin < (1 << 22); spin++) {
+              if (__hip_atomic_load(&xc->epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == F.epoch) break;
+              __builtin_amdgcn_s_sleep(1);
+            }
+            asm volatile("" ::: "memory");
+            shB[j] = __longlong_as_double((long long)__hip_atomic_load(&xc->B, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+          }
+        // (every group of the workgroup writes the same values; a wavefront's LDS operations complete in order, so the
+        // group's own lanes read below what its lanes wrote here)
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+      }
       unsigned long long const need = (1ull << e) - (1ull << (e - b));
       for (int spin = 0; spin < (1 << 22); spin++) {
         unsigned long long const rd = (unsigned long long)__hip_atomic_load(&sh_ready[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) |
@@ -566,15 +621,15 @@ int fm2_usable(int ND, int olen, int nblocks, int n_fm) {
 int launch_fm2(hipStream_t st, const float2 *baseband, size_t bb_stride, int olen, int nblocks, const DemodDesc *desc,
                DemodState *state, float *audio, int16_t *pcm, size_t pcm_stride, int pcm_big_endian, void *status,
                int status_stride, const int *fm_list, int n_fm, FmBlockStat *stat, const double *decay_pow, int parity,
-               const N0FinalArgs *n0final) {
+               const N0FinalArgs *n0final, Fm2Carry *xch, unsigned epoch) {
   if (nblocks <= 0 || n_fm <= 0) return 0;
   if ((olen != 256 && olen != 512) || nblocks > FM2_MAXT) {
     set_error("FM demodulator (workgroup per channel): olen %d / %d blocks unsupported", olen, nblocks);
     return -1;
   }
   N0FinalArgs const Z = n0final ? *n0final : N0FinalArgs{};
-  Fm2Args const F{nblocks, desc, state, parity, stat, status_stride, baseband, bb_stride, decay_pow, audio, pcm, pcm_stride,
-                  pcm_big_endian, static_cast<kh_status *>(status), status_stride, fm_list};
+  Fm2Args F{nblocks, desc, state, parity, stat, status_stride, baseband, bb_stride, decay_pow, audio, pcm, pcm_stride,
+            pcm_big_endian, static_cast<kh_status *>(status), status_stride, fm_list, 1, 0u, nullptr};
   int const G = olen / 8, ppw = 64 / G;
   // Channels per workgroup: one, or in a large bank (>= 1024 FM channels) as many as fill a wavefront's lanes with items.
   // Wavefronts: no more than give every item a group, and about as many as keep every workgroup resident at once (110
@@ -588,14 +643,37 @@ int launch_fm2(hipStream_t st, const float2 *baseband, size_t bb_stride, int ole
   if (cpw > FM2_MAXCPW) cpw = FM2_MAXCPW;
   while (cpw > 1 && cpw * nblocks > FM2_MAXT) cpw >>= 1;
   int const nwg = (n_fm + cpw - 1) / cpw;
-  int nw = 1; // a power of two: a workgroup's wavefronts then spread evenly over a CU's four SIMDs
-  while (nw < 16 && 2 * nw * nwg <= 5120 && nw * ppw < cpw * nblocks) nw *= 2;
+  // Wavefronts per workgroup: a power of two (they then spread evenly over a CU's four SIMDs)
+  auto waves_for = [&](int s) {
+    int const wg_items = (cpw * nblocks + s - 1) / s;
+    int nw = 1;
+    while (nw < 16 && 2 * nw * nwg * s <= 5120 && nw * ppw < wg_items) nw *= 2;
+    return nw;
+  };
+  // A small bank's channels are split over neighbouring workgroups (see the kernel): as many as give every CU one
+  // workgroup at most, runs of at least four blocks, and no more wavefronts in all than half of what the chip holds --
+  // the other half belongs to the front half's kernels and, in a mixed bank, to the linear demodulators beside this one
+  // (config 3's share, 128 FM channels: two workgroups of 16 wavefronts per channel took the whole chip and the step
+  // went from 138 to 182 us).  xch == nullptr (a launch captured into a hipGraph would bake the epoch in): never.
+  // (KA9Q_HIP_FM2_SPLIT: read at every launch; 1: never, n: n workgroups per channel wherever there are that many blocks)
+  const char *const sp_s = getenv("KA9Q_HIP_FM2_SPLIT");
+  int const sp_env = sp_s ? atoi(sp_s) : 0;
+  int S = 1;
+  if (cpw == 1 && xch != nullptr) {
+    if (sp_env > 0)
+      S = std::min(std::min(sp_env, nblocks), 16);
+    else
+      for (int s = 2; s <= 8; s *= 2)
+        if (s * nwg <= 256 && nblocks / s >= 4 && waves_for(s) * nwg * s <= 2048) S = s;
+  }
+  F.splits = S, F.epoch = epoch, F.xch = xch;
+  int nw = waves_for(S);
   if (nw_env > 0) nw = nw_env > 16 ? 16 : nw_env;
   // KA9Q_HIP_FM2_ITERATE_ALL=1 (test switch, read at every launch): the squelch of every block from the iteration, none from r alone
   const char *const it_env = getenv("KA9Q_HIP_FM2_ITERATE_ALL");
   int const it_all = it_env ? atoi(it_env) : 0;
   float const r_lo = it_all ? 0.f : FM2_R_LO, r_hi = it_all ? INFINITY : FM2_R_HI;
-  dim3 const grid(nwg + (n0final ? n0final->ninputs : 0));
+  dim3 const grid(nwg * S + (n0final ? n0final->ninputs : 0));
   if (G == 32)
     hipLaunchKernelGGL(kh_fm_demod2<32>, grid, dim3(64 * nw), 0, st, F, nwg, Z, n_fm, cpw, r_lo, r_hi);
   else

@@ -60,6 +60,13 @@ struct FmBlockStat {
   float angsum;                  // sum of the discriminator angles of samples 1 .. olen-1 (fm.c:96)
   float2 first, last;            // y[0], y[olen-1]: sample 0's angle needs the block before (fm.c:86-87)
 };
+// kh_fm_demod2 with a channel's blocks split over several workgroups: a block's integrator carry-out for a zero carry-in
+// (bits of a double), and the epoch (launch number, never 0) of the launch that left it; [nchan][stat_stride], written and
+// read with agent-scope atomics only
+struct Fm2Carry {
+  unsigned long long B;
+  unsigned epoch, pad;
+};
 struct FmWork { // per sample: discriminator angle and the de-emphasis integrator run from a zero carry-in
   float ang, s0;
 };
@@ -262,7 +269,7 @@ int fm2_usable(int ND, int olen, int nblocks, int n_fm);
 int launch_fm2(hipStream_t st, const float2 *baseband, size_t bb_stride, int olen, int nblocks, const DemodDesc *desc,
                DemodState *state, float *audio, int16_t *pcm, size_t pcm_stride, int pcm_big_endian, void *status,
                int status_stride, const int *fm_list, int n_fm, FmBlockStat *stat, const double *decay_pow, int parity,
-               const N0FinalArgs *n0final);
+               const N0FinalArgs *n0final, Fm2Carry *xch = nullptr, unsigned epoch = 0);
 
 // audio.c:32-135: one kh_rtp_chunk per PCM chunk of <= 480 words (plan: [nchan][plan_stride]), kh_rtp_state per channel
 int launch_rtp_plan(hipStream_t st, const int16_t *pcm, size_t pcm_stride, int olen, int nblocks, int nchan,

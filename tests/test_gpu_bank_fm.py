@@ -184,9 +184,12 @@ def test_fm_demodulator_arrangements_are_bit_identical(hip, monkeypatch, shape):
     x = synth.wideband_fm(0, T * calls * L, fs, N, sigs)
     x[: T * L // 2] *= 0.02  # the weaker carriers' squelches open during the first launch
     results = {}
-    for cpw, waves in ((0, 0), (1, 1), (1, 2), (1, 16), (2, 1), (2, 3), (4, 4), (8, 1), (8, 16), (3, 5)):
+    # (third number: KA9Q_HIP_FM2_SPLIT, the workgroups a channel's blocks are dealt over -- what small banks do by themselves)
+    for cpw, waves, split in ((0, 0, 1), (1, 1, 1), (1, 2, 1), (1, 16, 1), (2, 1, 1), (2, 3, 1), (4, 4, 1), (8, 1, 1), (8, 16, 1),
+                              (3, 5, 1), (0, 0, 0), (0, 0, 2), (1, 1, 3), (1, 4, 5), (1, 16, 7), (1, 2, 4)):
         monkeypatch.setenv("KA9Q_HIP_FM2_CPW", str(cpw))
         monkeypatch.setenv("KA9Q_HIP_FM2_WAVES", str(waves))
+        monkeypatch.setenv("KA9Q_HIP_FM2_SPLIT", str(split))
         bank = hip.Bank(L, M, D, 1, len(ks), T, fs)
         for c, k in enumerate(ks):
             bank.set_channel(c, demod=hip.KH_DEMOD_FM, rotate=synth.rotate_for(k, 12500.0, N, fs), low=-5500.0, high=5500.0,
@@ -201,9 +204,56 @@ def test_fm_demodulator_arrangements_are_bit_identical(hip, monkeypatch, shape):
                 out.append(np.concatenate([np.asarray(st[f], np.float64).ravel() for f in
                                            ("bb_power", "snr", "foffset", "pdeviation", "output_level", "squelch_open")]))
         bank.close()
-        results[(cpw, waves)] = out
-    ref = results[(0, 0)]
+        results[(cpw, waves, split)] = out
+    ref = results[(0, 0, 1)]
     assert np.abs(ref[0]).max() > 500 and any(np.abs(r).max() == 0 for r in ref[0])  # open and squelched channels
+    for key, out in results.items():
+        for a, b in zip(ref, out):
+            assert np.array_equal(a, b, equal_nan=True), key
+
+
+@pytest.mark.parametrize("shape", [(8_000_000, 131072, 131073, 256, 32, 1), (1_000_000, 8192, 8193, 32, 16, 3)])
+def test_fm_demodulator_split_channels_are_bit_identical(hip, monkeypatch, shape):
+    """A small bank deals a channel's blocks over neighbouring workgroups of kh_fm_demod2 (a run of blocks each; the runs'
+    integrator carry-outs cross through global memory: fm.c:110-111 is linear in lastaudio).  BASELINE configs[1]'s launch
+    shape (32 blocks of 512 samples; 4 workgroups per channel by default) and 16 blocks of 256: PCM, status and the state
+    carried into the next launch must not depend on the split -- none (1), the default (0), 2, 8, and one that does not
+    divide the block count.  Carriers that stay open through every run, one that opens in the middle of a launch (its
+    integrator then starts inside a later run), one that closes (decaying carry across runs), idle channels."""
+    fs, L, M, D, T, _ = shape
+    N = L + M - 1
+    ks = [-3, -2, -1, 0, 1, 2, 3]
+    steady = [(k, a, 300.0 + 35 * (k + 5), 2500.0) for k, a in ((0, 0.1), (1, 0.02), (3, 0.004))]
+    keyed = [(k, a, 300.0 + 35 * (k + 5), 2500.0) for k, a in ((-3, 0.05), (-2, 0.01))]
+    n = 2 * T * L
+    gate = np.ones(n, np.float32)
+    gate[: 5 * T * L // 8] = 0                      # the keyed carriers come up in the middle of the first launch
+    gate[11 * T * L // 8: 13 * T * L // 8] = 0      # and drop for a while in the second: a decaying carry across the runs
+    x = (synth.wideband_fm(0, n, fs, N, steady) + gate * synth.wideband_fm(0, n, fs, N, keyed, sigma=0.0)).astype(np.complex64)
+    results = {}
+    for split in (1, 0, 2, 8, 5):
+        monkeypatch.setenv("KA9Q_HIP_FM2_SPLIT", str(split))
+        bank = hip.Bank(L, M, D, 1, len(ks), T, fs)
+        for c, k in enumerate(ks):
+            bank.set_channel(c, demod=hip.KH_DEMOD_FM, rotate=synth.rotate_for(k, 12500.0, N, fs), low=-5500.0, high=5500.0,
+                             kaiser_beta=3.0, flat=int(k == 1))
+        out = []
+        for call in range(2):
+            bank.write_input(0, x[call * T * L:(call + 1) * T * L])
+            bank.execute(T)
+            out.append(np.stack([bank.pcm(c, T) for c in range(len(ks))]))
+            for c in range(len(ks)):
+                st = bank.status(c, T)
+                out.append(np.concatenate([np.asarray(st[f], np.float64).ravel() for f in
+                                           ("bb_power", "snr", "foffset", "pdeviation", "output_level", "squelch_open")]))
+        bank.close()
+        results[split] = out
+    ref = results[1]
+    assert np.abs(ref[0]).max() > 500 and any(np.abs(r).max() == 0 for r in ref[0])  # open and squelched channels
+    sq = ref[1][-T:]  # channel 0's (a keyed carrier's) squelch_open over the first launch: closed, then open
+    assert sq[0] == 0 and sq[-1] == 1
+    sq2 = ref[1 + len(ks) + 1][-T:]  # and over the second: open, closed, open again
+    assert sq2[0] == 1 and sq2.min() == 0 and sq2[-1] == 1
     for key, out in results.items():
         for a, b in zip(ref, out):
             assert np.array_equal(a, b, equal_nan=True), key

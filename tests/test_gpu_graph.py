@@ -124,3 +124,59 @@ def test_mixed_bank_demodulators_side_by_side_or_in_sequence(hip, monkeypatch):
     for j, (a, c) in enumerate(zip(*snaps)):
         assert np.array_equal(a[0], c[0]) and a[1] == c[1] and a[2] == c[2], j
     assert np.abs(snaps[0][-1][0][C - 2:]).max() > 100  # the linear channels produce audio
+
+
+@pytest.mark.parametrize("mixed", [False, True])
+def test_back_half_queued_by_the_banks_own_thread(hip, monkeypatch, mixed):
+    """KA9Q_HIP_ENQ_THREAD=1: kh_bank_execute queues the front half and returns; a thread of the bank's own queues the
+    hand-over, the back half and the slot's event.  Same kernels, same arguments, same order on every stream: bit-identical
+    to launches queued by the caller -- several launches in flight (no host sync in between), through the streaming ring as
+    well, with a channel retuned in the middle (kh_bank_set_channel has to wait for the thread) and the mode's switches
+    (keep_baseband, graphs on and off again) flipped while it is running."""
+    banks = []
+    for env in ("0", "1"):
+        monkeypatch.setenv("KA9Q_HIP_ENQ_THREAD", env)  # read by kh_bank_create
+        sigs, (b,) = _banks(hip, 1, hip.KH_PT_IQ16LE, mixed)
+        banks.append(b)
+    raw = _raw(hip, sigs)
+    pos = 0
+    for j, nb in enumerate(LAUNCHES):
+        seg = raw[2 * pos:2 * (pos + nb * L)]
+        outs = []
+        for b in banks:
+            if j == 5:
+                b.set_channel(0, demod=hip.KH_DEMOD_FM, rotate=synth.rotate_for(-2, 12500.0, N, FS), low=-5500.0, high=5500.0, kaiser_beta=3.0)
+            if j == 8:
+                b.keep_baseband(0)
+            if j == 12:
+                b.use_graph(1)
+            if j == 17:
+                b.use_graph(0)
+            b.write_input(0, seg, count=nb * L)
+            b.execute(nb, sync=False)
+            if j % 4 == 3 or j == len(LAUNCHES) - 1:
+                outs.append(_snapshot(b, nb))
+        if outs:
+            assert np.array_equal(outs[0][0], outs[1][0]), j
+            assert outs[0][1] == outs[1][1] and outs[0][2] == outs[1][2], j
+        pos += nb * L
+    assert np.abs(outs[1][0]).max() > 100
+    # the streaming ring on the same banks
+    for b in banks:
+        b.stream_open(3)
+    pos = 0
+    for j, nb in enumerate(LAUNCHES[:9]):
+        outs = []
+        for b in banks:
+            slot = b.stream_slot(0, np.int16, 2 * nb * L)
+            slot[:] = raw[2 * pos:2 * (pos + nb * L)]
+            b.stream_submit(nb)
+            if j % 3 == 2:
+                outs.append(_snapshot(b, nb))
+        if outs:
+            assert np.array_equal(outs[0][0], outs[1][0]), j
+            assert outs[0][1] == outs[1][1] and outs[0][2] == outs[1][2], j
+        pos += nb * L
+    for b in banks:
+        b.stream_close()
+        b.close()
