@@ -264,7 +264,10 @@ __host__ __device__ constexpr int chan2_waves(int npairs) { return (npairs + C2S
 
 // Workgroups [0, nchan_wg) carry C2_WAVES channel wavefronts each; the rest are compute_n0's second iteration
 // (radio.c:451-462, kh_n0.cuh) over N0_GX slices per (input, block), as in kh_back_a.
-constexpr int C2_WAVES = 2;
+// Four wavefronts, one per SIMD: beside the transform's passes (four wavefronts of 105-109 VGPRs fill a SIMD's register
+// file; one of this kernel's 152-VGPR wavefronts displaces a whole workgroup of a pass from its CU) a resident workgroup
+// then costs the pass exactly one of its own.  With two: channel stage 14.4 instead of 13.1 us alone at configs[1].
+constexpr int C2_WAVES = 4;
 template <int RB, int OCC>
 __global__ __launch_bounds__(64 * C2_WAVES, OCC) void kh_chan2(Chan2Args A, N0Pass1Args Z, int nchan_wg, int nwaves) {
   __shared__ __attribute__((aligned(16))) float2 ex[C2_WAVES * C2_WAVE_LDS];
