@@ -126,7 +126,12 @@ struct kh_bank {
   std::vector<float> noise_gains;
   std::vector<HostOsc> lo2, doppler;
   std::vector<float> gain;
-  std::vector<size_t> fill; // samples present in each input's raw ring
+  std::vector<size_t> fill; // samples present in each input's raw ring, from sample `head` on
+  // The unread samples of every input start `head` samples into its ring: a launch moves the head instead of the
+  // samples (a latency-mode caller writes T*L samples and consumes them with T calls of execute(1): moving what is left
+  // after every launch was T-1 copy-engine operations between the front stream's kernels per launch).  The ring is
+  // compacted only when a write would run past its end (ring_compact), and the head returns to 0 whenever a launch empties it.
+  size_t head = 0;
   std::vector<int> lists;
   int n_fm = 0, n_lin = 0, n_am = 0;
   int n_lin_nopll = 0; // the linear list holds the channels without PLL first
@@ -671,6 +676,24 @@ int kh_bank_set_gain(kh_bank *b, unsigned int input, float gain_factor) {
 // the stream the front half (ingest, ring compaction) is issued on outside profiling passes: raw-ring writes go
 // there too, so that they are ordered behind a launch that still reads the ring (KA9Q_HIP_PIPELINE=0: one stream)
 static hipStream_t raw_stream(kh_bank *b) { return b->pipeline ? b->front : b->stream; }
+// Moves every input's unread samples to the start of its ring, ordered behind the front halves that still read them (same
+// stream).  The move is by `head` samples, so pieces of at most `head` samples never overlap their own destination, and
+// they go in ascending order on the one stream: each lands where the piece before it has already been read.
+static int ring_compact(kh_bank *b) {
+  if (b->head == 0) return 0;
+  hipStream_t const ws = raw_stream(b);
+  for (int i = 0; i < b->P; i++) {
+    unsigned char *base = b->d_raw + i * b->raw_stride;
+    for (size_t off = 0; off < b->fill[i]; off += b->head) {
+      size_t const n = std::min(b->head, b->fill[i] - off);
+      if (!KH_HIP(hipMemcpyAsync(base + payload_bytes(b->cfg.payload, off), base + payload_bytes(b->cfg.payload, b->head + off),
+                                 payload_bytes(b->cfg.payload, n), hipMemcpyDeviceToDevice, ws)))
+        return -1;
+    }
+  }
+  b->head = 0;
+  return 0;
+}
 
 int kh_bank_write_input(kh_bank *b, unsigned int input, const void *payload, size_t count) {
   if (!b || input >= (unsigned)b->P || (!payload && count)) return -1;
@@ -679,7 +702,8 @@ int kh_bank_write_input(kh_bank *b, unsigned int input, const void *payload, siz
     set_error("kh_bank_write_input: ring overflow (%zu + %zu > %zu samples)", b->fill[input], count, cap);
     return -1;
   }
-  unsigned char *dst = b->d_raw + input * b->raw_stride + payload_bytes(b->cfg.payload, b->fill[input]);
+  if (b->head + b->fill[input] + count > cap && ring_compact(b)) return -1;
+  unsigned char *dst = b->d_raw + input * b->raw_stride + payload_bytes(b->cfg.payload, b->head + b->fill[input]);
   // on the stream the front half runs on: behind the ingest of any launch still reading the ring
   hipStream_t const ws = raw_stream(b);
   if (!KH_HIP(hipMemcpyAsync(dst, payload, payload_bytes(b->cfg.payload, count), hipMemcpyDefault, ws)))
@@ -695,7 +719,8 @@ int kh_bank_write_zeros(kh_bank *b, unsigned int input, size_t count) {
     set_error("kh_bank_write_zeros: ring overflow");
     return -1;
   }
-  unsigned char *dst = b->d_raw + input * b->raw_stride + payload_bytes(b->cfg.payload, b->fill[input]);
+  if (b->head + b->fill[input] + count > cap && ring_compact(b)) return -1;
+  unsigned char *dst = b->d_raw + input * b->raw_stride + payload_bytes(b->cfg.payload, b->head + b->fill[input]);
   if (!KH_HIP(hipMemsetAsync(dst, 0, payload_bytes(b->cfg.payload, count), raw_stream(b)))) return -1;
   b->fill[input] += count;
   return 0;
@@ -709,6 +734,11 @@ int kh_bank_raw_device_ptr(kh_bank *b, unsigned int input, void **dptr, size_t *
 int kh_bank_commit_input(kh_bank *b, unsigned int input, size_t count) {
   if (!b || input >= (unsigned)b->P) return -1;
   if (count > (size_t)b->T * b->cfg.L) return -1;
+  // (kh_bank_raw_device_ptr is the START of the ring: whatever was left unread is dropped with the head)
+  if (b->head) {
+    for (auto &f : b->fill) f = 0;
+    b->head = 0;
+  }
   b->fill[input] = count;
   return 0;
 }
@@ -832,6 +862,7 @@ int kh_bank_stream_submit(kh_bank *b, unsigned int nblocks) {
   // (KA9Q_HIP_STREAM_HOSTWAIT=1: the host waits for the transfer instead, and no stream waits for another)
   if (b->stream_hostwait ? !KH_HIP(hipEventSynchronize(b->ev_h2d[e])) : !KH_HIP(hipStreamWaitEvent(fs, b->ev_h2d[e], 0))) return -1;
   b->d_raw = b->d_raw_buf[dev];
+  b->head = 0;
   for (int i = 0; i < b->P; i++) b->fill[i] = (size_t)nblocks * b->cfg.L;
   int const rc = kh_bank_execute(b, nblocks);
   if (rc) return rc;
@@ -931,9 +962,10 @@ static int enqueue_front(kh_bank *b, hipStream_t st, unsigned int nblocks, bool 
   bool const fused_carry = (size_t)(M - 1) <= need;
   // large transforms read the raw ring themselves (fused convert + IF power + history) unless an oscillator is active
   bool const fused = b->fused_now;
-  FftIngest const fi{b->d_raw, b->raw_stride, (unsigned)payload_bytes(b->cfg.payload, (size_t)b->T * L), b->cfg.payload,
+  const unsigned char *const raw = b->d_raw + payload_bytes(b->cfg.payload, b->head); // the first unread sample of input 0
+  FftIngest const fi{raw, b->raw_stride, (unsigned)payload_bytes(b->cfg.payload, (size_t)b->T * L - b->head), b->cfg.payload,
                      time, b->d_time[b->cur ^ 1], b->time_stride, b->d_idesc, b->d_energy[sp], M};
-  if (!fused && launch_ingest(st, b->d_raw, b->raw_stride, b->cfg.payload, time + (M - 1), b->time_stride, b->d_idesc,
+  if (!fused && launch_ingest(st, raw, b->raw_stride, b->cfg.payload, time + (M - 1), b->time_stride, b->d_idesc,
                               b->d_energy[sp], L, nblocks, P, fused_carry ? b->d_time[b->cur ^ 1] : nullptr,
                               need - (fused_carry ? (M - 1) : 0)))
     return -1;
@@ -1225,11 +1257,11 @@ int kh_bank_execute(kh_bank *b, unsigned int nblocks) {
   } else {
     kh_bank::GraphEntry *g = nullptr;
     for (auto &x : b->graphs)
-      if (x.nblocks == nblocks && x.cur == b->cur && x.fmpar == b->fm_parity && x.sp == sp && x.raw == b->d_raw &&
+      if (x.nblocks == nblocks && x.cur == b->cur && x.fmpar == b->fm_parity && x.sp == sp && x.raw == b->d_raw + payload_bytes(b->cfg.payload, b->head) &&
           x.pipelined == (sf != sb) && x.fused == b->fused_now && x.masked == b->masked_now)
         g = &x;
     if (!g) { // first sight: run eagerly (this also warms the twiddle tables, which allocate)
-      b->graphs.push_back(kh_bank::GraphEntry{nblocks, b->cur, b->fm_parity, sp, b->d_raw, sf != sb, b->fused_now, b->masked_now, 0, nullptr, nullptr});
+      b->graphs.push_back(kh_bank::GraphEntry{nblocks, b->cur, b->fm_parity, sp, b->d_raw + payload_bytes(b->cfg.payload, b->head), sf != sb, b->fused_now, b->masked_now, 0, nullptr, nullptr});
       g = &b->graphs.back();
     }
     rc = run_half(b, sf, nblocks, enqueue_front, &g->front, g->seen);
@@ -1258,24 +1290,13 @@ int kh_bank_execute(kh_bank *b, unsigned int nblocks) {
   b->cur ^= 1;
   b->last_sp = sp;
   b->sp = (sp + 1) % b->nslots;
-  // consume the raw ring
+  // consume the raw ring: the head moves, the samples stay (ring_compact moves them when a write needs the room)
+  bool empty = true;
   for (int i = 0; i < P; i++) {
-    size_t const rest = b->fill[i] - need;
-    if (rest) {
-      // Move what is left to the head of the ring, ordered behind the ingest on its stream.  The move is by `need`
-      // samples, so pieces of at most `need` samples never overlap their own destination; with more than one launch
-      // queued (a latency-mode caller that writes T*L samples and consumes them with execute(1)) the pieces go in
-      // ascending order on the one stream, each landing where the piece before it has already been read.
-      unsigned char *base = b->d_raw + i * b->raw_stride;
-      for (size_t off = 0; off < rest; off += need) {
-        size_t const n = std::min(need, rest - off);
-        if (!KH_HIP(hipMemcpyAsync(base + payload_bytes(b->cfg.payload, off), base + payload_bytes(b->cfg.payload, off + need),
-                                   payload_bytes(b->cfg.payload, n), hipMemcpyDeviceToDevice, sf)))
-          return -1;
-      }
-    }
-    b->fill[i] = rest;
+    b->fill[i] -= need;
+    if (b->fill[i]) empty = false;
   }
+  b->head = empty ? 0 : b->head + need;
   b->last_blocks = nblocks;
   if (prof) {
     if (!KH_HIP(hipStreamSynchronize(sb))) return -1;

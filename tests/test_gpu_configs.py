@@ -345,8 +345,8 @@ def test_back_to_back_launches_match_synchronised_ones(hip, monkeypatch, pipelin
 
 
 def test_full_ring_consumed_one_block_at_a_time(hip):
-    """A latency-mode caller: T*L samples written at once, then consumed with execute(1) T times (the ring is compacted
-    after every launch while more than one launch of samples is still queued).  Every block must match the same
+    """A latency-mode caller: T*L samples written at once, then consumed with execute(1) T times (every launch moves the
+    ring's read offset; nothing is copied).  Every block must match the same
     samples run as one execute(T): PCM +-1 LSB, status 1e-4 -- and nothing may be processed twice."""
     fs, L, M, D, C, T = 1_000_000, 8192, 8193, 32, 3, 6
     N = L + M - 1
@@ -379,6 +379,69 @@ def test_full_ring_consumed_one_block_at_a_time(hip):
         single.execute(1)
     whole.close()
     single.close()
+
+
+@pytest.mark.parametrize("payload_name", ["KH_PT_CF32", "KH_PT_IQ16LE"])
+def test_ring_is_compacted_when_a_write_needs_the_room(hip, payload_name):
+    """The raw ring keeps a read offset: a launch moves it, and the unread samples are moved to the start of the ring only
+    when a write would run past the end -- by fewer samples than are left (several pieces, in ascending order) and by more
+    (one piece).  A caller that tops the ring up between launches of different lengths must get what a caller gets that
+    writes and consumes the same samples launch by launch: PCM +-1 LSB (launches of other lengths take other kernels),
+    status 1e-4, over the whole sequence and with no sample processed twice or skipped."""
+    fs, L, M, D, C, T = 1_000_000, 8192, 8193, 32, 3, 6
+    N = L + M - 1
+    payload = getattr(hip, payload_name)
+    sigs = [(-2, 0.05, 400.0, 2500.0), (0, 0.02, 700.0, 2000.0), (3, 0.1, 1000.0, 3000.0)]
+    total = 16
+    x = np.ascontiguousarray(synth.wideband_fm(6, total * L, fs, N, sigs), np.complex64)
+    if payload == hip.KH_PT_IQ16LE:
+        raw = np.empty(2 * x.size, np.int16)
+        raw[0::2] = np.clip(np.rint(x.real * 32767 * 4), -32768, 32767)
+        raw[1::2] = np.clip(np.rint(x.imag * 32767 * 4), -32768, 32767)
+        per = 2
+    else:
+        raw, per = x, 1
+    banks = []
+    for _ in range(2):
+        b = hip.Bank(L, M, D, 1, C, T, fs, payload=payload, compute_n0=1, n0_low=-5500.0, n0_high=5500.0)
+        for c, (k, *_r) in enumerate(sigs):
+            b.set_channel(c, demod=hip.KH_DEMOD_FM, rotate=synth.rotate_for(k, 12500.0, N, fs), low=-5500.0, high=5500.0,
+                          kaiser_beta=3.0)
+        banks.append(b)
+    plain, ring = banks
+    olen = L // D
+    # (blocks written, then the launches that follow): the ring holds 6 blocks
+    script = [(6, [1]),        # offset 1, 5 left
+              (1, [1, 1]),     # 1 + 5 + 1 > 6: moved by 1 block in 5 pieces; then offset 2, 4 left
+              (2, [1, 2, 1]),  # 2 + 4 + 2 > 6: moved by 2 blocks in 2 pieces; offset 4, 2 left
+              (3, [2, 3]),     # 4 + 2 + 3 > 6: moved by 4 blocks in one piece; everything consumed: offset back to 0
+              (4, [4])]        # a plain launch from the start of the ring again
+    wpos = rpos = 0
+    for nwrite, launches in script:
+        ring.write_input(0, raw[wpos * L * per:(wpos + nwrite) * L * per], count=nwrite * L)
+        wpos += nwrite
+        for nb in launches:
+            ring.execute(nb)
+            plain.write_input(0, raw[rpos * L * per:(rpos + nb) * L * per], count=nb * L)
+            plain.execute(nb)
+            for c in range(C):
+                d = np.abs(ring.pcm(c, nb).astype(np.int32) - plain.pcm(c, nb).astype(np.int32))
+                assert d.max() <= 1, (rpos, nb, c, int(d.max()))
+                a, w = ring.status(c, nb), plain.status(c, nb)
+                for key in ("bb_power", "snr"):
+                    assert np.all(np.abs(a[key] - w[key]) <= 1e-4 * np.abs(w[key]) + 1e-4), (key, rpos, c)
+                assert np.array_equal(a["squelch_open"], w["squelch_open"])
+            assert ring.input_status(0, nb).tobytes() == plain.input_status(0, nb).tobytes() or \
+                np.allclose(ring.input_status(0, nb)["if_power"], plain.input_status(0, nb)["if_power"], rtol=1e-5)
+            rpos += nb
+    assert rpos == wpos == total
+    assert np.abs(ring.pcm(0, 4)).max() > 100
+    with pytest.raises(Exception):  # the ring is empty
+        ring.execute(1)
+    with pytest.raises(Exception):  # and it still refuses what does not fit
+        ring.write_input(0, raw[:7 * L * per], count=7 * L)
+    plain.close()
+    ring.close()
 
 
 @pytest.mark.parametrize("case", ["inband", "outband", "noise"])
