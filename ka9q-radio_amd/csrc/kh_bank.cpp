@@ -253,6 +253,7 @@ static void enq_main(kh_bank *b) {
     int rc = w.rc;
     if (!rc) {
       hipStream_t const sb = b->stream;
+      // (waiting for the front half on this thread instead, with no barrier in the back stream's queue, was tried: +-0.5 us)
       if (!KH_HIP(hipStreamWaitEvent(sb, b->ev_front_done[j.sp], 0))) rc = -1;
       if (!rc) rc = enqueue_back_job(b, sb, j, false);
       if (!rc && !KH_HIP(hipEventRecord(b->ev_back_done[j.sp], sb))) rc = -1;
@@ -1215,13 +1216,19 @@ int kh_bank_execute(kh_bank *b, unsigned int nblocks) {
   }
   b->launch_no++;
   if (sf != b->front && !KH_HIP(hipStreamSynchronize(b->front))) return -1; // an earlier pipelined front half
-  // the back half that last read slot sp (nslots launches ago) must be done before the front half overwrites it.  With
-  // two slots that back half ends about when this front half is dispatched, and a wait that really blocks across
-  // hardware queues costs ~10 us; with three it has long finished
-  // (asked on the host first: a wait that is already satisfied would still put a barrier packet into the front queue,
-  // and the command processor spends microseconds on each)
-  if (sf != sb && b->slot_used[sp] && hipEventQuery(b->ev_back_done[sp]) != hipSuccess &&
-      !KH_HIP(hipStreamWaitEvent(sf, b->ev_back_done[sp], 0)))
+  // The back half that last read slot sp (nslots launches ago) must be done before the front half overwrites it.  The
+  // HOST waits for it (KA9Q_HIP_SLOT_HOSTWAIT=0: the front stream does).  A caller that queues launches faster than the
+  // GPU runs them -- any throughput loop -- finds that back half still pending, and a wait left to the front stream is a
+  // barrier packet across hardware queues in front of every column pass: 3 us of a 58 us step at configs[1], 7 of 120 at
+  // config 4's share, although the barrier is long satisfied when the queue reaches it (profiles/r03_step_anatomy.txt).
+  // Waiting here costs nothing the GPU notices: the caller stays at most nslots launches ahead, i.e. two whole launches
+  // are queued behind the running one.  (In the other mode the host asks first: a wait that is already satisfied would
+  // still put its barrier into the queue.)
+  static int const slot_hostwait = getenv("KA9Q_HIP_SLOT_HOSTWAIT") ? atoi(getenv("KA9Q_HIP_SLOT_HOSTWAIT")) : 1;
+  if (slot_hostwait && sf != sb && b->slot_used[sp]) {
+    if (!KH_HIP(hipEventSynchronize(b->ev_back_done[sp]))) return -1;
+  } else if (sf != sb && b->slot_used[sp] && hipEventQuery(b->ev_back_done[sp]) != hipSuccess &&
+             !KH_HIP(hipStreamWaitEvent(sf, b->ev_back_done[sp], 0)))
     return -1;
   (void)hipGetLastError(); // hipEventQuery's hipErrorNotReady is not an error
   // (a copy-engine operation between two kernels of a stream costs a hand-over in each direction: the descriptors
