@@ -143,9 +143,16 @@ def stage_bytes(bincount, n0_rides, kept_bins=None):
     }
 
 
-def time_steps(bank, step, steps, warm=5):
-    for _ in range(warm):
+def time_steps(bank, step, steps, warm=5, warm_s=0.15):
+    # (at least `warm` steps and warm_s seconds, so that the clocks have left their idle state: 40 steps of config 4's share
+    # timed after five warm-up steps came to 118 us per step where 200 steps after a warm-up give 111)
+    t0 = time.perf_counter()
+    k = 0
+    while k < warm or time.perf_counter() - t0 < warm_s:
         step()
+        k += 1
+        if k % 8 == 0:
+            bank.sync()
     bank.sync()
     t0 = time.perf_counter()
     for _ in range(steps):
@@ -252,7 +259,7 @@ def shapes_leg(pyka9q, torch, device):
     ]
     for shape, plan, nb, label, key in jobs:
         try:
-            out.append(measure_shape(pyka9q, torch, device, shape, plan, nb, label, steps=10 if shape.P > 1 else 40, valu_key=key))
+            out.append(measure_shape(pyka9q, torch, device, shape, plan, nb, label, steps=10 if shape.P > 1 else 100, valu_key=key))
         except Exception as e:  # an extra leg must never cost the bench line
             out.append({"workload": label, "error": repr(e)})
     return out

@@ -183,6 +183,7 @@ struct kh_bank {
   };
   BackEnq *enq = nullptr;
   int enq_thread = 0;
+  unsigned evflags = hipEventDisableTiming; // of the events that order the bank's own streams
   // hipGraph cache: the kernel sequence of one execute call, captured the second time a shape is seen
   struct GraphEntry {
     unsigned nblocks;
@@ -424,7 +425,16 @@ kh_bank *kh_bank_create(const struct kh_bank_config *cfg) {
   b->side_prio = use_prio ? prio_hi : 0;
   b->side_use_prio = use_prio;
   if (const char *e = getenv("KA9Q_HIP_DEMOD_FORK")) b->demod_fork = atoi(e);
-  unsigned const evflags = hipEventDisableTiming;
+  // The hand-over events between the bank's streams (front half done, back half done) are recorded without the
+  // system-scope fence that hipEventRecord performs by default (hipEventDisableSystemFence; KA9Q_HIP_EVENT_FENCE=1: with
+  // it).  They order kernels of ONE device -- every kernel ends with a release at agent scope, which is what the other
+  // stream's kernels need -- and the host reads nothing on their account: what it reads, it reads through copies queued on
+  // the back stream and a stream synchronisation, which fence for the host by themselves.  The fence is a cache write-back
+  // and invalidation in the queue after each half: 2 us of a 54.5 us step at configs[1], 2 of 113 at config 4's share
+  // (2, a device-scope release, hipEventReleaseToDevice: no gain).
+  static int const ev_fence = getenv("KA9Q_HIP_EVENT_FENCE") ? atoi(getenv("KA9Q_HIP_EVENT_FENCE")) : 0;
+  unsigned const evflags = hipEventDisableTiming | (ev_fence == 0 ? (unsigned)hipEventDisableSystemFence : ev_fence == 2 ? (unsigned)hipEventReleaseToDevice : 0u);
+  b->evflags = evflags; // (the fork and join events of a mixed bank's demodulators as well)
   for (auto &e : b->ev_front_done) ok = ok && KH_HIP(hipEventCreateWithFlags(&e, evflags));
   for (auto &e : b->ev_back_done) ok = ok && KH_HIP(hipEventCreateWithFlags(&e, evflags));
   ok = ok && KH_HIP(hipHostMalloc((void **)&b->h_idesc, kh_bank::IDESC_SLOTS * P * sizeof(IngestDesc), hipHostMallocDefault));
@@ -947,7 +957,7 @@ static int upload_channels(kh_bank *b) {
 static bool n0_in_fft(const kh_bank *b);
 static int n0_direct(const kh_bank *b);
 // KA9Q_HIP_DIAG_SKIP (measurement only, results are garbage): 1 queues no back-half kernels, 2 no front-half kernels --
-// what a step costs with one half's kernels alone, events and hand-overs as ever
+// what a step costs with one half's kernels alone, events and hand-overs as ever; 4: see kh_bank_execute
 static int diag_skip() {
   static int const v = getenv("KA9Q_HIP_DIAG_SKIP") ? atoi(getenv("KA9Q_HIP_DIAG_SKIP")) : 0;
   return v;
@@ -1087,8 +1097,7 @@ static int enqueue_back_job(kh_bank *b, hipStream_t st, kh_bank::BackJob const &
   if (fork && b->side == nullptr) {
     bool ok = b->side_use_prio ? KH_HIP(hipStreamCreateWithPriority(&b->side, hipStreamNonBlocking, b->side_prio))
                                : KH_HIP(hipStreamCreateWithFlags(&b->side, hipStreamNonBlocking));
-    ok = ok && KH_HIP(hipEventCreateWithFlags(&b->ev_fork, hipEventDisableTiming)) &&
-         KH_HIP(hipEventCreateWithFlags(&b->ev_join, hipEventDisableTiming));
+    ok = ok && KH_HIP(hipEventCreateWithFlags(&b->ev_fork, b->evflags)) && KH_HIP(hipEventCreateWithFlags(&b->ev_join, b->evflags));
     if (!ok) fork = false;
   }
   hipStream_t const sl = fork ? b->side : st;
@@ -1276,8 +1285,11 @@ int kh_bank_execute(kh_bank *b, unsigned int nblocks) {
       g->seen = -1;
       rc = enqueue_front(b, sf, nblocks, false);
     }
+    // (KA9Q_HIP_DIAG_SKIP & 4: the back stream does NOT wait for the front half -- a planted hazard that
+    // tools/stress_handover.py has to find)
     if (!rc && sf != sb &&
-        (!KH_HIP(hipEventRecord(b->ev_front_done[sp], sf)) || !KH_HIP(hipStreamWaitEvent(sb, b->ev_front_done[sp], 0))))
+        (!KH_HIP(hipEventRecord(b->ev_front_done[sp], sf)) ||
+         (!(diag_skip() & 4) && !KH_HIP(hipStreamWaitEvent(sb, b->ev_front_done[sp], 0)))))
       rc = -1;
     if (!rc) {
       rc = run_half(b, sb, nblocks, enqueue_back, &g->back, g->seen);
