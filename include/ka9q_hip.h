@@ -241,7 +241,9 @@ int kh_bank_stream_submit(kh_bank *, unsigned int nblocks);
 int kh_bank_stream_close(kh_bank *);                      /* waits for everything in flight; NULL -> 0 */
 /* one pass of the hot path over nblocks (<= max_blocks) blocks of every input: convert + mix (a7),
  * forward FFT (a2), compute_n0 (a8), per channel bin-select x response x IFFT (a4), demod (a9-a12),
- * scaleclip (a14).  Asynchronous on the bank's stream; kh_bank_sync waits.  0 or -1. */
+ * scaleclip (a14).  Asynchronous on the bank's streams; kh_bank_sync waits.  A caller may run ahead of the GPU by three
+ * launches: the call blocks until the launch three before this one has finished (its spectrum slot is the one this
+ * launch overwrites).  0 or -1. */
 int kh_bank_execute(kh_bank *, unsigned int nblocks);
 int kh_bank_sync(kh_bank *);
 /* results of the last execute (host pointers; these calls synchronise) */
