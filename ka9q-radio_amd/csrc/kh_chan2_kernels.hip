@@ -98,16 +98,54 @@ __device__ __forceinline__ void c2_products(v2f (&v)[C2_RA], const float2 *__res
   }
 }
 
+// The same in two steps, for the wavefronts whose response comes through LDS: the bins are REQUESTED before the response
+// and the twiddles are parked in LDS (a wavefront otherwise goes through four memory round trips one after the other --
+// twiddles, channel descriptor, response, bins -- which was half of its 8 us at 4096 channels), and multiplied afterwards.
+// Same operands in the same order as c2_products: bit-identical.
+template <int RB, bool FAST>
+__device__ __forceinline__ void c2_load_bins(float2 (&bins)[C2_RA], const float2 *__restrict__ fd, int m0, int l, int N) {
+  constexpr int ND = C2_RA * RB, H = ND / 2 + 1;
+  if constexpr (FAST) {
+    const float2 *fl = fd + m0 + l;
+#pragma unroll
+    for (int a = 0; a < C2_RA; a++) {
+      if (a == 16) {
+        bins[a] = fd[m0 + ((l - 1) & (ND - 1))];
+      } else {
+        int const off = RB * a + (a < 16 ? ND - H : -H); // >= 0
+        bins[a] = fl[off];
+      }
+    }
+  } else {
+#pragma unroll
+    for (int a = 0; a < C2_RA; a++) {
+      int const i = (RB * a + l - H) & (ND - 1);
+      int m = m0 + i;
+      if (m >= N) m -= N;
+      bins[a] = fd[m];
+    }
+  }
+}
+template <int RB>
+__device__ __forceinline__ void c2_mul(v2f (&v)[C2_RA], const float2 *rp /*LDS*/, float2 const (&bins)[C2_RA]) {
+#pragma unroll
+  for (int a = 0; a < C2_RA; a++) v[a] = pk::cmul(pk::load(rp[RB * a]), pk::load(bins[a]));
+}
+
 // pairs are numbered block-fastest: pair q = ch * nblocks + b.  A wavefront's pairs are then blocks b .. b+3 of one
 // channel (one response fetch serves them) when a launch has several blocks, and neighbouring channels when it has one.
-template <int RB>
-__device__ __forceinline__ void chan2_wave(Chan2Args const &A, float2 *exw, const float2 *twl, int w, int lane64) {
+// Called by EVERY wavefront of a channel workgroup (there is a workgroup barrier inside): `active` false = a wavefront beyond
+// the launch's last, which computes on the last pair and stores nothing.  twr: this thread's share of the stage-A twiddle
+// table, requested by the caller before anything else; it is parked in twl (LDS) here, behind the requests for the bins.
+template <int RB, int TWK>
+__device__ __forceinline__ void chan2_wave(Chan2Args const &A, float2 *exw, float2 *twl, float2 const (&twr)[TWK], int tw_stride,
+                                           int w, int lane64, bool active) {
   using S = C2Shape<RB>;
   constexpr int RA = C2_RA, ND = S::ND, OLEN = S::OLEN, PITCH = S::PITCH, H = S::H;
   static_assert(RB == 32 || RB == 16, "N_dec = 1024 or 512");
   int const g = lane64 / RB, l = lane64 % RB;
   int q = w * S::PAIRS + g;
-  bool const valid = q < A.npairs;
+  bool const valid = active && q < A.npairs;
   if (!valid) q = A.npairs - 1; // padding pair: computes on the last pair, stores nothing
   int const ch = A.magic ? (int)__umulhi((unsigned)q, A.magic) : q, b = q - ch * A.nblocks; // (magic == 0: one block per launch)
   float2 *ex = exw + g * S::PAIR_LDS;
@@ -125,15 +163,26 @@ __device__ __forceinline__ void chan2_wave(Chan2Args const &A, float2 *exw, cons
   if (m0 < 0) m0 += N;
   bool const fast = __builtin_amdgcn_ballot_w64(m0 + ND > N) == 0;
   v2f v[RA]; // (packed pairs: kh_regfft.cuh)
-  if (one_channel) {
+  float2 rr[ND / 64], bins[RA];
+  if (one_channel) { // requests only: the response (contiguous), then the bins
     const float2 *rc = A.response + (size_t)ch * ND + lane64;
 #pragma unroll
-    for (int k = 0; k < ND / 64; k++) exw[lane64 + 64 * k] = rc[64 * k];
-    c2_wave_sync();
+    for (int k = 0; k < ND / 64; k++) rr[k] = rc[64 * k];
     if (fast)
-      c2_products<RB, true>(v, exw + l, fd, m0, l, N);
+      c2_load_bins<RB, true>(bins, fd, m0, l, N);
     else
-      c2_products<RB, false>(v, exw + l, fd, m0, l, N);
+      c2_load_bins<RB, false>(bins, fd, m0, l, N);
+  }
+  // the twiddles (every wavefront of the workgroup its share) and this wavefront's response go to LDS
+#pragma unroll
+  for (int k = 0; k < TWK; k++) twl[threadIdx.x + tw_stride * k] = twr[k];
+  if (one_channel) {
+#pragma unroll
+    for (int k = 0; k < ND / 64; k++) exw[lane64 + 64 * k] = rr[k];
+  }
+  __syncthreads(); // (the workgroup's only barrier: twl; it orders this wavefront's own region as well)
+  if (one_channel) {
+    c2_mul<RB>(v, exw + l, bins);
     c2_wave_sync(); // (the exchange below reuses the region)
   } else {
     const float2 *rp = A.response + (size_t)ch * ND + l;
@@ -273,8 +322,11 @@ __global__ __launch_bounds__(64 * C2_WAVES, OCC) void kh_chan2(Chan2Args A, N0Pa
   __shared__ __attribute__((aligned(16))) float2 ex[C2_WAVES * C2_WAVE_LDS];
   __shared__ float2 twl[C2_RA * RB]; // stage A's twiddles, [c][l]: one coalesced copy per workgroup instead of 31 loads per lane
   if ((int)blockIdx.x < nchan_wg) {
-    for (int k = threadIdx.x; k < C2_RA * RB; k += 64 * C2_WAVES) twl[k] = A.tw[k];
-    __syncthreads();
+    constexpr int TWK = C2_RA * RB / (64 * C2_WAVES);
+    static_assert(TWK * 64 * C2_WAVES == C2_RA * RB, "the twiddle table divides evenly over the workgroup");
+    float2 twr[TWK]; // requested first, parked in LDS inside chan2_wave
+#pragma unroll
+    for (int k = 0; k < TWK; k++) twr[k] = A.tw[threadIdx.x + 64 * C2_WAVES * k];
     // workgroups are dealt round-robin over the 8 XCDs (b and b + 8 share one), each with an L2 of its own: XCD x takes a
     // contiguous eighth of the pairs, so that the bins neighbouring channels share (a 12.5 kHz raster reads every bin
     // 2.5 times) are fetched into ONE L2 once instead of into several from HBM (speed only; any placement is correct)
@@ -282,7 +334,8 @@ __global__ __launch_bounds__(64 * C2_WAVES, OCC) void kh_chan2(Chan2Args A, N0Pa
     int const wg = ((int)blockIdx.x & 7) * per + ((int)blockIdx.x >> 3);
     int const wave = threadIdx.x >> 6;
     int const w = wg * C2_WAVES + wave;
-    if (w < nwaves) chan2_wave<RB>(A, ex + wave * C2_WAVE_LDS, twl, w, threadIdx.x & 63);
+    bool const active = w < nwaves; // (uniform per wavefront; the others go through the motions for the barrier's sake)
+    chan2_wave<RB, TWK>(A, ex + wave * C2_WAVE_LDS, twl, twr, 64 * C2_WAVES, active ? w : nwaves - 1, threadIdx.x & 63, active);
   } else {
     // (bracket mode's tasks were also tried inside the channel workgroups -- requested before the channel work, finished
     // after it: the 40 registers they hold across it cost the 4096-channel bank 12 us and gained 2 us here)
