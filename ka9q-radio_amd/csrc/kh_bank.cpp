@@ -1106,7 +1106,9 @@ static int enqueue_back_job(kh_bank *b, hipStream_t st, kh_bank::BackJob const &
   }
   if (back2 && b->n_fm > 0 &&
       launch_fm2(st, b->d_bb, b->bb_stride, b->olen, nblocks, b->d_ddesc, b->d_dstate, b->keep_audio ? b->d_audio : nullptr, b->d_pcm,
-                 b->pcm_stride, b->cfg.pcm_big_endian, b->d_status, b->T, b->d_lists, b->n_fm, b->d_fmstat, b->d_decaypow,
+                 b->pcm_stride, b->cfg.pcm_big_endian, b->d_status, b->T,
+                 b->n_fm == C ? nullptr : b->d_lists /* all FM: the list is the identity, and a load the kernel's first step can do without */,
+                 b->n_fm, b->d_fmstat, b->d_decaypow,
                  job.fm_parity, ride_final ? &nf : nullptr,
                  b->use_graph ? nullptr : b->d_fm2x /* a captured launch would replay its epoch */,
                  (++b->fm2_epoch ? b->fm2_epoch : ++b->fm2_epoch)))

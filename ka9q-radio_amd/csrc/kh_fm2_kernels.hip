@@ -211,7 +211,7 @@ __global__ __launch_bounds__(1024) void kh_fm_demod2(Fm2Args F, int nfm_wg, N0Fi
       Fm2Chan c{};
       c.ch = -1;
       if (chi < n_fm) {
-        c.ch = F.list[chi];
+        c.ch = F.list ? F.list[chi] : chi; // (null: every channel of the bank is an FM channel, the list is the identity)
         const DemodDesc *dd = F.descs + c.ch;
         const DemodState *st = F.states + c.ch;
         c.flat = dd->flat, c.dsamprate = dd->dsamprate, c.gain = dd->fm_gain;
@@ -224,7 +224,7 @@ __global__ __launch_bounds__(1024) void kh_fm_demod2(Fm2Args F, int nfm_wg, N0Fi
     if (es < items) {
       int const ce = es / nblocks, be = es - ce * nblocks, che = ce * nfm_wg + wgc;
       if (che < n_fm) {
-        const FmBlockStat *fs = F.stat + (size_t)F.list[che] * F.stat_stride + be;
+        const FmBlockStat *fs = F.stat + (size_t)(F.list ? F.list[che] : che) * F.stat_stride + be;
         float const bbp = fs->bb_power, var = fs->variance, r = fs->snr;
         sh_bbp[es] = bbp, sh_var[es] = var, sh_r[es] = r;
         it_valid = be >= b_lo && be < b_hi; // (the iteration and its status word: this workgroup's blocks only)
