@@ -13,9 +13,9 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _run(env_extra, bursts, seed):
+def _run(env_extra, bursts, seed, *more):
     env = dict(os.environ, **env_extra)
-    return subprocess.run([sys.executable, os.path.join(ROOT, "tools", "stress_handover.py"), str(bursts), str(seed)], env=env,
+    return subprocess.run([sys.executable, os.path.join(ROOT, "tools", "stress_handover.py"), str(bursts), str(seed), *more], env=env,
                           capture_output=True, text=True, timeout=200)
 
 
@@ -29,3 +29,11 @@ def test_bursts_of_launches_match_synchronised_ones(env):
 def test_a_planted_hazard_is_found():
     r = _run({"KA9Q_HIP_DIAG_SKIP": "4"}, 40, 12)
     assert r.returncode != 0 and "DIFFERENT" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+def test_bursts_of_launches_on_a_mixed_bank():
+    """the linear / AM demodulators on their own stream beside the FM demodulator: the fork and the join are two more events
+    of the same kind"""
+    r = _run({}, 300, 13, "mixed")
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert "0 bad" in r.stdout

@@ -7,7 +7,8 @@ events at all).  After every burst: PCM of every channel, per-channel status and
 bit for bit.  What this guards: the events that order the two streams carry no system-scope fence
 (hipEventDisableSystemFence) and the host waits for a slot's last reader (KA9Q_HIP_SLOT_HOSTWAIT).
 
-usage: tools/stress_handover.py [bursts] [seed]"""
+usage: tools/stress_handover.py [bursts] [seed] [mixed]   (mixed: the last four channels are USB with hang AGC and envelope AM --
+their demodulators run on a third stream beside the FM demodulator, forked and joined by two more such events)"""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "ka9q-radio_amd"))
@@ -16,6 +17,7 @@ import pyka9q as hip, synth
 
 bursts = int(sys.argv[1]) if len(sys.argv) > 1 else 300
 seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+mixed = len(sys.argv) > 3 and sys.argv[3] == "mixed"
 rng = np.random.default_rng(seed)
 fs, L, M, D, C, T = 8_000_000, 131072, 131073, 256, 16, 4
 N = L + M - 1
@@ -33,8 +35,15 @@ def make(env):
     for k, val in env.items():
         os.environ[k] = val
     b = hip.Bank(L, M, D, 1, C, T, fs, compute_n0=1, n0_low=-5500.0, n0_high=5500.0)
+    out_rate = fs / D
     for c, k in enumerate(ks):
-        b.set_channel(c, demod=hip.KH_DEMOD_FM, rotate=synth.rotate_for(k, 12500.0, N, fs), low=-5500.0, high=5500.0, kaiser_beta=3.0)
+        rot = synth.rotate_for(k, 12500.0, N, fs)
+        if mixed and c >= C - 4:
+            b.set_channel(c, demod=hip.KH_DEMOD_LINEAR, rotate=rot, low=100.0 if c % 2 else -5000.0, high=3000.0 if c % 2 else 5000.0,
+                          kaiser_beta=3.0, pll=0, agc=1, env=int(c % 2 == 0), hangtime=1.1 * out_rate,
+                          recovery_rate=10 ** ((6.0 / out_rate) / 20), agc_gain=1e3)
+        else:
+            b.set_channel(c, demod=hip.KH_DEMOD_FM, rotate=rot, low=-5500.0, high=5500.0, kaiser_beta=3.0)
     for k in env:
         del os.environ[k]
     return b
