@@ -717,6 +717,14 @@ __device__ __forceinline__ void cispi_small(double x, double *sn, double *cs) {
 }
 
 // ================================================================ linear: linear.c:57-156, one lane per channel
+// PLL_ONLY: the PLL pass alone (linear.c:64-108: lock counter, the per-sample loop 81-97 with the sample written back as
+// linear.c:91 does, the block's cphase / foffset / snr) for channels whose output pass (linear.c:114-148) is left to
+// kh_demod_linear_w behind this kernel.  The two passes are separate loops in the reference and the second reads only what
+// the first wrote back; here the serial part of a PLL channel -- a recurrence of ~60 dependent operations per sample, most
+// of them fp64, on one lane -- sheds the ~100 instructions per sample of the output pass, which a workgroup per channel
+// does in parallel (config 5, 256 PLL channels: 18.75 -> 10.77 ms per step).  Writes the PLL's status words and state
+// fields only.
+template <bool PLL_ONLY>
 __global__ __launch_bounds__(64) void kh_demod_linear(float2 *__restrict__ baseband, size_t bb_stride, int olen,
                                                       int nblocks, const DemodDesc *__restrict__ descs,
                                                       DemodState *__restrict__ states, float *__restrict__ audio,
@@ -818,6 +826,10 @@ __global__ __launch_bounds__(64) void kh_demod_linear(float2 *__restrict__ baseb
           signal += v.x * v.x;
           noise += v.y * v.y;
         }
+        if constexpr (PLL_ONLY) {
+          yb[n] = v; // linear.c:91
+          continue;
+        }
         // linear.c:114-148
         // complex float * complex double -> double product, rounded to float
         float2 sm = v;
@@ -878,12 +890,33 @@ __global__ __launch_bounds__(64) void kh_demod_linear(float2 *__restrict__ baseb
       } else
         s.snr = NAN;
     }
+    if constexpr (PLL_ONLY) { // the PLL's words of the record; kh_demod_linear_w writes the others
+      kh_status *const rp = status + (size_t)ch * status_stride + b;
+      rp->snr = s.snr;
+      rp->foffset = r.foffset;
+      rp->cphase = r.cphase;
+      rp->lock_timer = r.lock_timer;
+      rp->pll_lock = s.pll_lock;
+      continue;
+    }
     r.output_level = output_level / (olen * d.channels);
     r.bb_power = energy / olen;
     r.snr = s.snr;
     r.pll_lock = s.pll_lock;
     r.agc_gain = s.agc_gain;
     status[(size_t)ch * status_stride + b] = r;
+  }
+  if constexpr (PLL_ONLY) { // (the PLL's fields; shift oscillator, gain and hang counter belong to kh_demod_linear_w)
+    DemodState *const sp = states + ch;
+    sp->lock_count = s.lock_count;
+    sp->pll_lock = s.pll_lock;
+    sp->snr = s.snr;
+    sp->pll_integrator = s.pll_integrator;
+    sp->vco_freq = s.vco_freq;
+    sp->vco_re = vco.re;
+    sp->vco_im = vco.im;
+    sp->vco_steps = vco.steps;
+    return;
   }
   s.shift_re = shift.re;
   s.shift_im = shift.im;
@@ -1092,12 +1125,14 @@ __global__ __launch_bounds__(64 * LW_WAVES) void kh_demod_linear_w(float2 *__res
     if (lane == 0) { // (field by field: a local record here is an alloca that the compiler moves to LDS, 60 KB a workgroup)
       kh_status *const r = status + (size_t)ch * status_stride + b;
       r->bb_power = energy_sum / olen;
-      r->snr = s.snr;
-      r->foffset = 0.f;
+      if (!d.pll) { // (a PLL channel's output pass: kh_demod_linear<true> has written these five before this kernel)
+        r->snr = s.snr;
+        r->foffset = 0.f;
+        r->cphase = 0.f;
+        r->lock_timer = 0.f;
+        r->pll_lock = s.pll_lock;
+      }
       r->pdeviation = 0.f;
-      r->cphase = 0.f;
-      r->lock_timer = 0.f;
-      r->pll_lock = s.pll_lock;
       r->output_level = level / (olen * d.channels);
       r->agc_gain = gain_after;
       r->squelch_open = 0;
@@ -1519,7 +1554,13 @@ int launch_demod(hipStream_t st, float2 *baseband, size_t bb_stride, int olen, i
   // the first n_lin_nopll entries of lin_list have opt.pll off: one workgroup each (kh_demod_linear_w); the others keep
   // the lane-per-channel loop.  KA9Q_HIP_LINEAR_WAVE=0 sends every linear channel there (A/B switch).
   static int const lin_wave_env = getenv("KA9Q_HIP_LINEAR_WAVE") ? atoi(getenv("KA9Q_HIP_LINEAR_WAVE")) : 1;
-  int const nw = (lin_wave_env && olen <= 1024 && nblocks <= LW_MAXB) ? (n_lin_nopll < n_lin ? n_lin_nopll : n_lin) : 0;
+  // KA9Q_HIP_PLL_SPLIT=0: PLL channels keep both passes in the lane-per-channel loop.  Default: the PLL pass there
+  // (kh_demod_linear<true>), the output pass by kh_demod_linear_w behind it, like every other linear channel's.
+  static int const pll_split_env = getenv("KA9Q_HIP_PLL_SPLIT") ? atoi(getenv("KA9Q_HIP_PLL_SPLIT")) : 1;
+  bool const lw_ok = lin_wave_env && olen <= 1024 && nblocks <= LW_MAXB;
+  int const n_nopll = n_lin_nopll < n_lin ? n_lin_nopll : n_lin;
+  bool const pll_split = lw_ok && pll_split_env && n_lin > n_nopll;
+  int const nw = lw_ok ? (pll_split ? n_lin : n_nopll) : 0;
   if (n_fm > 0) {
     if (olen < 2 || olen > 8192 - 1) {
       set_error("FM demodulator: olen %d outside [2, 8192]", olen);
@@ -1549,13 +1590,16 @@ int launch_demod(hipStream_t st, float2 *baseband, size_t bb_stride, int olen, i
     else
       hipLaunchKernelGGL(kh_fm_finish_w<16>, grid, dim3(64 * wpb), 0, st, F, npairs, nfin, Z);
   }
+  if (pll_split) // the PLL pass of the channels that have one, ahead of their output pass
+    hipLaunchKernelGGL(kh_demod_linear<true>, dim3((n_lin - n_nopll + 63) / 64), dim3(64), 0, st, baseband, bb_stride, olen, nblocks,
+                       desc, state, audio, pcm, pcm_stride, pcm_big_endian, stt, status_stride, lin_list + n_nopll, n_lin - n_nopll);
   if (nw > 0) {
     auto const kern = olen <= 256 ? kh_demod_linear_w<4> : olen <= 512 ? kh_demod_linear_w<8> : kh_demod_linear_w<16>;
     hipLaunchKernelGGL(kern, dim3(nw), dim3(64 * LW_WAVES), 0, st, baseband, bb_stride, olen, nblocks, desc, state, audio, pcm, pcm_stride,
                        pcm_big_endian, stt, status_stride, lin_list);
   }
   if (n_lin - nw > 0)
-    hipLaunchKernelGGL(kh_demod_linear, dim3((n_lin - nw + 63) / 64), dim3(64), 0, st, baseband, bb_stride, olen, nblocks,
+    hipLaunchKernelGGL(kh_demod_linear<false>, dim3((n_lin - nw + 63) / 64), dim3(64), 0, st, baseband, bb_stride, olen, nblocks,
                        desc, state, audio, pcm, pcm_stride, pcm_big_endian, stt, status_stride, lin_list + nw, n_lin - nw);
   if (n_am > 0)
     hipLaunchKernelGGL(kh_demod_am, dim3((n_am + 63) / 64), dim3(64), 0, st, baseband, bb_stride, olen, nblocks, desc,
