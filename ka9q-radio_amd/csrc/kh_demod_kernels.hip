@@ -1556,7 +1556,8 @@ int launch_demod(hipStream_t st, float2 *baseband, size_t bb_stride, int olen, i
   static int const lin_wave_env = getenv("KA9Q_HIP_LINEAR_WAVE") ? atoi(getenv("KA9Q_HIP_LINEAR_WAVE")) : 1;
   // KA9Q_HIP_PLL_SPLIT=0: PLL channels keep both passes in the lane-per-channel loop.  Default: the PLL pass there
   // (kh_demod_linear<true>), the output pass by kh_demod_linear_w behind it, like every other linear channel's.
-  static int const pll_split_env = getenv("KA9Q_HIP_PLL_SPLIT") ? atoi(getenv("KA9Q_HIP_PLL_SPLIT")) : 1;
+  // (read at every launch: tests/test_gpu_bank_linear.py runs one process under both)
+  int const pll_split_env = getenv("KA9Q_HIP_PLL_SPLIT") ? atoi(getenv("KA9Q_HIP_PLL_SPLIT")) : 1;
   bool const lw_ok = lin_wave_env && olen <= 1024 && nblocks <= LW_MAXB;
   int const n_nopll = n_lin_nopll < n_lin ? n_lin_nopll : n_lin;
   bool const pll_split = lw_ok && pll_split_env && n_lin > n_nopll;

@@ -259,3 +259,50 @@ def test_agc_runs_and_record_scan(hip, dec):
                 assert abs(st["agc_gain"] - sig["agc_gain"]) <= 1e-4 * abs(sig["agc_gain"]), (c, call, b, st["agc_gain"], sig["agc_gain"])
     assert all(cases[c]["input"] == 1 and cases[c]["hangtime"] < 960 for c, _, _ in ties), ties  # only where ties are at home
     bank.close()
+
+
+def test_pll_channels_one_loop_or_two_kernels(hip, monkeypatch):
+    """PLL channels run the PLL pass (linear.c:81-97) in the lane-per-channel loop and the output pass (linear.c:114-148)
+    in kh_demod_linear_w behind it; KA9Q_HIP_PLL_SPLIT=0 keeps both in the one loop, as the reference's thread does.  The
+    second pass reads only what the first wrote back (linear.c:91), so the PLL's own words (snr, foffset, cphase, lock
+    timer, lock) are bit-identical, and so is everything while the gain stands still (no AGC, or a hang that outlasts the
+    run).  Where the gain recovers sample by sample the two kernels' products part by an ulp now and then (the lane loop
+    multiplies in sequence, kh_demod_linear_w lays the products out in runs: both inside the oracle's bars, which
+    test_linear_and_am_bank holds the default to): audio to 2e-6 of its peak, PCM +-1 LSB, agc_gain to 1e-6, bb_power and
+    output_level (sums in another order) to 1e-5 -- block after block over four launches, mono and envelope outputs, with and without squaring."""
+    T, calls = 4, 4
+    n = T * calls * L
+    sig = {"am": _signal("am", n).astype(np.complex64), "dsb": _signal("dsb", n).astype(np.complex64)}
+    chans = [dict(input=0, low=-5000.0, high=5000.0, pll=1, agc=1, hangtime=1.1 * 48000, recovery_rate=RECOVERY, agc_gain=AGC0),
+             dict(input=1, low=-5000.0, high=5000.0, pll=1, square=1, agc=1, hangtime=0.0, recovery_rate=RECOVERY, agc_gain=AGC0),
+             dict(input=0, low=-5000.0, high=5000.0, pll=1, env=1, agc=1, hangtime=300.0, recovery_rate=RECOVERY, agc_gain=AGC0),
+             dict(input=0, low=-5000.0, high=5000.0, pll=1, agc=0, agc_gain=3.0),
+             dict(input=1, low=100.0, high=3000.0, pll=0, agc=1, hangtime=1.1 * 48000, recovery_rate=RECOVERY, agc_gain=AGC0)]
+    runs = {}
+    for split in ("0", "1"):
+        monkeypatch.setenv("KA9Q_HIP_PLL_SPLIT", split)  # read at every launch
+        bank = hip.Bank(L, M, D, 2, len(chans), T, FS)
+        for c, kw in enumerate(chans):
+            bank.set_channel(c, demod=hip.KH_DEMOD_LINEAR, headroom=HEADROOM, **kw)
+        out = []
+        for call in range(calls):
+            bank.write_input(0, sig["am"][call * T * L:(call + 1) * T * L])
+            bank.write_input(1, sig["dsb"][call * T * L:(call + 1) * T * L])
+            bank.execute(T)
+            out.append(([bank.pcm(c, T).copy() for c in range(len(chans))], [bank.audio(c, T).copy() for c in range(len(chans))],
+                        [bank.status(c, T).copy() for c in range(len(chans))]))
+        bank.close()
+        runs[split] = out
+    for call, ((p0, a0, s0), (p1, a1, s1)) in enumerate(zip(runs["0"], runs["1"])):
+        for c in range(len(chans)):
+            still = c in (3, 4) or (c == 0 and call > 0)  # no AGC / the hang AGC once its first attack is over
+            if still:
+                assert np.array_equal(p0[c], p1[c]) and np.array_equal(a0[c], a1[c]), (call, c)
+            assert np.abs(p0[c].astype(np.int32) - p1[c].astype(np.int32)).max() <= 1, (call, c)
+            assert np.abs(a0[c] - a1[c]).max() <= 2e-6 * np.abs(a0[c]).max(), (call, c)
+            for key in ("snr", "foffset", "cphase", "lock_timer", "pll_lock"):
+                assert np.array_equal(s0[c][key], s1[c][key], equal_nan=True), (key, call, c)
+            assert np.allclose(s0[c]["agc_gain"], s1[c]["agc_gain"], rtol=1e-6, atol=0), (call, c)
+            for key in ("bb_power", "output_level"):  # (960 terms added in sample order / by a wavefront's tree)
+                assert np.allclose(s0[c][key], s1[c][key], rtol=1e-5, atol=0), (key, call, c)
+    assert np.abs(runs["1"][-1][0][0]).max() > 100
