@@ -18,6 +18,10 @@ def _run(exe, thread):
     env = dict(os.environ, KA9Q_HIP_ENQ_THREAD=str(thread), ASAN_OPTIONS="detect_leaks=0:protect_shadow_gap=0",
                UBSAN_OPTIONS="print_stacktrace=1:halt_on_error=1")
     r = subprocess.run([exe], env=env, capture_output=True, text=True, timeout=300)
+    # (an instrumented binary that cannot set up its shadow memory on this machine is an environment matter, not a finding)
+    if "_san" in exe and r.returncode != 0 and not r.stdout.strip() and re.search(
+            r"ReserveShadowMemoryRange|Shadow memory range interleaves|failed to (mmap|allocate)|ASan runtime does not come first", r.stderr):
+        pytest.skip("the AddressSanitizer runtime does not start here: " + r.stderr.strip().splitlines()[0][:200])
     assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-3000:]
     assert "ERROR: AddressSanitizer" not in r.stderr and "runtime error" not in r.stderr, r.stderr[-3000:]
     m = re.search(r"bank_san: ok, checksum ([0-9a-f]{16})", r.stdout)
