@@ -813,9 +813,12 @@ __global__ __launch_bounds__(64) void kh_demod_linear(float2 *__restrict__ baseb
           // run_pll, osc.c:91-107
           float feedback = d.pll_integrator_gain * s.pll_integrator + d.pll_prop_gain * phase;
           s.pll_integrator += phase;
-          feedback = (double)feedback > 0.49 ? (float)0.49 : (double)feedback < -0.49 ? (float)-0.49 : feedback;
-          // set_osc(&pll->vco, feedback, 0), osc.c:22-36
-          if (isnan(vco.re) || isnan(vco.im) || vco.re * vco.re + vco.im * vco.im < 0.9) {
+          // osc.c:96: the comparisons are in double against 0.49; the float next above 0.49 is (float)0.49 itself and the
+          // one below it is below 0.49, so they are these float comparisons (a NaN passes through, as there)
+          feedback = feedback >= 0.49f ? 0.49f : feedback <= -0.49f ? -0.49f : feedback;
+          // set_osc(&pll->vco, feedback, 0), osc.c:22-36: is_phasor_init's isnan(re) || isnan(im) || cnrm(phasor) < 0.9 in
+          // one comparison (a NaN in either part makes the norm NaN, and NaN >= 0.9 is false)
+          if (!(vco.re * vco.re + vco.im * vco.im >= 0.9)) {
             vco.re = 1;
             vco.im = 0;
             vco.steps = 0;
